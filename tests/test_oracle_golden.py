@@ -1,0 +1,127 @@
+"""CPU: the oracle (oracle/fdn_oracle.py) against the fixtures produced by the reference itself.
+
+This is what pins the oracle (the reference ships no tests/golden vectors of its own)."""
+import pytest
+import torch
+
+import fdn_oracle as O
+from common import assert_close_cond, fdn_weights, fixture, fixture_weights, lpnet_weights, rel_rms
+
+F32, F64 = torch.float32, torch.float64
+
+
+def _both(fn, sd, *xs):
+    """Run an oracle function in fp32 and fp64."""
+    with torch.no_grad():
+        y32 = fn(O.cast_params(sd, F32), *[x.to(F32) if x is not None else None for x in xs])
+        y64 = fn(O.cast_params(sd, F64), *[x.to(F64) if x is not None else None for x in xs])
+    return y32, y64
+
+
+@pytest.mark.parametrize("name", ["fdsa_c32", "fdsa_c64", "fdsa_c128"])
+def test_fdsa(name):
+    fx = fixture(name)
+    sd = fixture_weights(name, fx["shapes"])
+    y32, y64 = _both(lambda P, x: O.fdsa(x, P, ""), {"." + k: v for k, v in sd.items()}, fx["x"])
+    assert_close_cond(y32, fx["y"], y64, name)
+
+
+@pytest.mark.parametrize("name", ["fdffn_c32", "fdffn_c64", "fdffn_c128"])
+def test_fdffn(name):
+    fx = fixture(name)
+    sd = fixture_weights(name, fx["shapes"])
+    y32, y64 = _both(lambda P, x: O.fdffn(x, P, ""), {"." + k: v for k, v in sd.items()}, fx["x"])
+    assert_close_cond(y32, fx["y"], y64, name)
+    assert rel_rms(y32, fx["y"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["fcaffn_c32_32x32", "fcaffn_c32_24x40", "fcaffn_c64_46x40", "fcaffn_c128_16x16"])
+def test_fcaffn(name):
+    fx = fixture(name)
+    sd = fixture_weights(name, fx["shapes"])
+    y32, y64 = _both(lambda P, x, a, p, i: O.fcaffn(x, a, p, i, P, ""), {"." + k: v for k, v in sd.items()},
+                     fx["x"], fx["amp"], fx["pha"], fx["img"])
+    assert_close_cond(y32, fx["y"], y64, name)
+
+
+@pytest.mark.parametrize("name,light", [("tblock_enc_c32", True), ("tblock_dec_c32", False)])
+def test_tblock(name, light):
+    fx = fixture(name)
+    sd = fixture_weights(name, fx["shapes"], po_scale=float(fx["po_scale"]))
+    y32, y64 = _both(lambda P, x, a, p, i: O.tblock(x, a, p, i, P, "", True, light), {"." + k: v for k, v in sd.items()},
+                     fx["x"], fx["amp"], fx["pha"], fx["img"])
+    assert_close_cond(y32, fx["y"], y64, name)
+
+
+def test_fuse():
+    fx = fixture("fuse_n32")
+    sd = fixture_weights("fuse_n32", fx["shapes"])
+    y32, y64 = _both(lambda P, e, d: O.fuse(e, d, P, ""), {"." + k: v for k, v in sd.items()}, fx["enc"], fx["dnc"])
+    assert_close_cond(y32, fx["y"], y64, "fuse")
+
+
+def test_resample_and_embed():
+    for name, fn in (("downsample_c32", O.downsample), ("upsample_c64", O.upsample)):
+        fx = fixture(name)
+        sd = fixture_weights(name, fx["shapes"])
+        y32, y64 = _both(lambda P, x: fn(x, P, ""), {"." + k: v for k, v in sd.items()}, fx["x"])
+        assert_close_cond(y32, fx["y"], y64, name)
+    fx = fixture("patch_embed_3_32")
+    sd = fixture_weights("patch_embed_3_32", fx["shapes"])
+    with torch.no_grad():
+        y = torch.nn.functional.conv2d(fx["x"], sd["proj.weight"], padding=1)
+    assert rel_rms(y, fx["y"]) < 1e-6
+
+
+def test_mar_pieces():
+    fx = fixture("freblock_c12")
+    sd = fixture_weights("freblock_c12", fx["shapes"])
+    y32, y64 = _both(lambda P, x: O.freblock(x, P, ""), {"." + k: v for k, v in sd.items()}, fx["x"])
+    assert_close_cond(y32, fx["y"], y64, "freblock")
+    fx = fixture("fourier_fuse_84_12")
+    sd = fixture_weights("fourier_fuse_84_12", fx["shapes"])
+    y32, y64 = _both(lambda P, a, b, c: O.fourier_fuse(a, b, c, P, ""), {"." + k: v for k, v in sd.items()},
+                     fx["x1"], fx["x2"], fx["x4"])
+    assert_close_cond(y32, fx["y"], y64, "fourier_fuse")
+
+
+def test_mar_full():
+    fx = fixture("mar_full")
+    sd = fixture_weights("mar_full", fx["shapes"])
+    with torch.no_grad():
+        y3, y2, y1 = O.mar(fx["x"], fx["ratio"].view(-1, 1, 1, 1), {"net_a." + k: v for k, v in sd.items()}, "net_a")
+    for got, key in ((y3, "y3"), (y2, "y2"), (y1, "y1")):
+        assert O.psnr(got, fx[key]) > 110.0, key
+
+
+def test_lpnet_real_weights():
+    fx = fixture("lpnet_real")
+    P = lpnet_weights()
+    with torch.no_grad():
+        y = O.lpnet_forward(P, fx["x"])
+    assert torch.allclose(y, fx["y"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["fdn_tamed_64", "fdn_tamed_96x160"])
+def test_fdn_end_to_end_tamed(name):
+    fx = fixture(name)
+    sd = fdn_weights(tame=float(fx["tame"]))
+    with torch.no_grad():
+        out = O.fdn_forward(sd, fx["x"], fx["ratio"])
+    for got, key, floor in zip(out, ("y", "q1", "q2", "q3"), (100.0, 110.0, 110.0, 110.0)):
+        p = O.psnr(got, fx[key])
+        assert p > floor, f"{name}.{key}: PSNR {p:.1f} dB"
+
+
+def test_harness_u8():
+    fx = fixture("harness_u8")
+    img = fx["img"].numpy()
+    padded, h, w = O.harness_pre(img)
+    assert torch.equal(padded, fx["padded"])
+    with torch.no_grad():
+        ratio = O.lpnet_forward(lpnet_weights(), padded)
+        assert torch.allclose(ratio, fx["ratio"], atol=2e-6)
+        res = O.fdn_forward(fdn_weights(tame=float(fx["tame"])), padded, ratio)[0]
+    out = O.harness_post(res, h, w)
+    diff = (out.astype(int) - fx["out_u8"].numpy().astype(int))
+    assert abs(diff).max() <= 1 and (diff != 0).mean() < 1e-3
