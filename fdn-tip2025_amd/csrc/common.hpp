@@ -1,0 +1,44 @@
+// Shared helpers for the FDN gfx950 kernels (device math, launch checks, error codes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fdn_hip.h"
+
+#define FDN_CHECK_ARG(cond) \
+    do {                    \
+        if (!(cond)) return FDN_ERR_ARG; \
+    } while (0)
+
+static inline int fdn_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FDN_OK : FDN_ERR_LAUNCH;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    // F.gelu default (erf form), FDN_arch.py:427,438,473
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case FDN_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;   // LeakyReLU(0.1), FDN_arch.py:28
+        case FDN_ACT_RELU: return v > 0.f ? v : 0.f;
+        case FDN_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case FDN_ACT_GELU: return gelu_erf(v);
+        default: return v;
+    }
+}
+
+// replace_denormals on one component: (-1e-10, 1e-10) incl. +-0 -> +1e-10 (FDN_arch.py:548-553)
+__device__ __forceinline__ float rd1(float v) { return (v < 1e-10f && v > -1e-10f) ? 1e-10f : v; }
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ float cabs2(float2 a) { return sqrtf(a.x * a.x + a.y * a.y); }

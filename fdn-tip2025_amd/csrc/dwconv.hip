@@ -1,0 +1,152 @@
+// Depthwise 3x3 convolutions of the FDN path (HBM-bound stencil kernels, LDS halo tiles).
+//   fdn_dwconv3x3    : plain depthwise 3x3 (+activation)            FDN_arch.py:396-399,435-441
+//   fdn_dwconv_gate  : Conv2d(C,2C,3,groups=C) then gelu(x1)*x2     FDN_arch.py:472-473, 426-427
+//   fdn_img_mod_maps : conv3_{mul,add}(conv1_{mul,add}(x_img))      FDN_arch.py:423
+// Tile = 32 rows x 64 columns of one (b, c) plane per 256-thread workgroup; lane = column, so
+// global loads/stores and LDS reads are contiguous across the wave.
+#include "common.hpp"
+
+namespace {
+
+constexpr int TH = 32, TW = 64;
+constexpr int LW = TW + 2;       // halo width
+constexpr int LS = 68;           // LDS row stride (floats)
+
+// load a (TH+2) x (TW+2) halo tile of plane `src` (H x W) into LDS, zero outside the image
+__device__ __forceinline__ void load_halo(float (*t)[LS], const float* __restrict__ src, int H, int W, int y0, int x0) {
+    for (int i = threadIdx.x; i < (TH + 2) * LW; i += 256) {
+        const int r = i / LW, c = i - r * LW;
+        const int y = y0 - 1 + r, x = x0 - 1 + c;
+        t[r][c] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(long)y * W + x] : 0.f;
+    }
+}
+
+__device__ __forceinline__ float stencil(const float (*t)[LS], int r, int c, const float* w) {
+    // output at tile-local (r, c) ; halo origin is (-1,-1)
+    float a = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) a = fmaf(w[dy * 3 + dx], t[r + dy][c + dx], a);
+    return a;
+}
+
+__global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    float* __restrict__ out, int C, int H, int W, int act, int tiles_x) {
+    __shared__ float t[TH + 2][LS];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const long plane = ((long)b * C + c) * H * W;
+    load_halo(t, x + plane, H, W, ty0, tx0);
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = w[c * 9 + i];
+    __syncthreads();
+    const int cx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
+    const int gx = tx0 + cx;
+    if (gx >= W) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gy = ty0 + r0 + i;
+        if (gy < H) out[plane + (long)gy * W + gx] = apply_act(stencil(t, r0 + i, cx, wk), act);
+    }
+}
+
+__global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      float* __restrict__ out, int C, int H, int W, int tiles_x) {
+    __shared__ float ta[TH + 2][LS];
+    __shared__ float tb[TH + 2][LS];
+    const int j = blockIdx.y, b = blockIdx.z;
+    const int ca = j >> 1, cb = (C + j) >> 1;     // grouped conv: output o reads input o/2
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const long hw = (long)H * W;
+    load_halo(ta, x + ((long)b * C + ca) * hw, H, W, ty0, tx0);
+    load_halo(tb, x + ((long)b * C + cb) * hw, H, W, ty0, tx0);
+    float wa[9], wb[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        wa[i] = w[j * 9 + i];
+        wb[i] = w[(C + j) * 9 + i];
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
+    const int gx = tx0 + cx;
+    if (gx >= W) return;
+    float* dst = out + ((long)b * C + j) * hw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gy = ty0 + r0 + i;
+        if (gy < H) dst[(long)gy * W + gx] = gelu_erf(stencil(ta, r0 + i, cx, wa)) * stencil(tb, r0 + i, cx, wb);
+    }
+}
+
+// mul/add maps: per output channel c:  sum_tap w3[c][tap] * (sum_i w1[c][i] * img[i][p+tap])
+__global__ __launch_bounds__(256) void img_maps_kernel(const float* __restrict__ img, const float* __restrict__ w1m,
+                                                       const float* __restrict__ w3m, const float* __restrict__ w1a,
+                                                       const float* __restrict__ w3a, float* __restrict__ mul,
+                                                       float* __restrict__ add, int C, int H, int W, int tiles_x) {
+    __shared__ float t[3][TH + 2][LS];
+    const int b = blockIdx.z;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const long hw = (long)H * W;
+    for (int i = 0; i < 3; ++i) load_halo(t[i], img + ((long)b * 3 + i) * hw, H, W, ty0, tx0);
+    __syncthreads();
+    const int cx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
+    const int gx = tx0 + cx;
+    if (gx >= W) return;
+    // channel chunk handled by this workgroup (blockIdx.y): 8 channels
+    const int c0 = blockIdx.y * 8;
+    for (int c = c0; c < min(c0 + 8, C); ++c) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int gy = ty0 + r0 + r;
+            if (gy >= H) continue;
+            float am = 0.f, aa = 0.f;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                // inner sum over the 3 image channels first (same association as conv1 then conv3)
+                float sm = 0.f, sa = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float v = t[i][r0 + r + tp / 3][cx + tp % 3];
+                    sm = fmaf(w1m[c * 3 + i], v, sm);
+                    sa = fmaf(w1a[c * 3 + i], v, sa);
+                }
+                am = fmaf(w3m[c * 9 + tp], sm, am);
+                aa = fmaf(w3a[c * 9 + tp], sa, aa);
+            }
+            const long o = ((long)b * C + c) * hw + (long)gy * W + gx;
+            mul[o] = am;
+            add[o] = aa;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, int C, int H, int W, int act,
+                             fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && w && out && B > 0 && C > 0 && H > 0 && W > 0 && C < 65536 && B < 65536);
+    const int tx = cdiv(W, TW), ty = cdiv(H, TH);
+    hipLaunchKernelGGL(dw3x3_kernel, dim3(tx * ty, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, out, C, H, W,
+                       act, tx);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_dwconv_gate(const float* x, const float* w, float* out, int B, int C, int H, int W, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && w && out && B > 0 && C > 0 && H > 0 && W > 0 && C < 65536 && B < 65536);
+    const int tx = cdiv(W, TW), ty = cdiv(H, TH);
+    hipLaunchKernelGGL(dw_gate_kernel, dim3(tx * ty, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, out, C, H,
+                       W, tx);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_img_mod_maps(const float* img, const float* w1_mul, const float* w3_mul, const float* w1_add,
+                                const float* w3_add, float* mul, float* add, int B, int C, int H, int W,
+                                fdn_stream_t stream) {
+    FDN_CHECK_ARG(img && w1_mul && w3_mul && w1_add && w3_add && mul && add && B > 0 && C > 0 && H > 0 && W > 0);
+    const int tx = cdiv(W, TW), ty = cdiv(H, TH);
+    hipLaunchKernelGGL(img_maps_kernel, dim3(tx * ty, cdiv(C, 8), B), dim3(256), 0, static_cast<hipStream_t>(stream), img,
+                       w1_mul, w3_mul, w1_add, w3_add, mul, add, C, H, W, tx);
+    return fdn_launch_status();
+}

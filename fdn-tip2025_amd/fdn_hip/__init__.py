@@ -1,0 +1,80 @@
+"""ctypes binding of libfdn_hip.so (the C ABI declared in include/fdn_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every compute step
+of the FDN path is a call into the library.  There is NO CPU or eager fallback: if the shared
+library is missing, or a tensor is not a contiguous fp32 ROCm tensor, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfdn_hip.so")
+_lib = None
+
+ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
+PRO_NONE, PRO_LN, PRO_LN3_GATE, PRO_LN_MULADD = 0, 1, 2, 3
+EPI_NONE, EPI_RES, EPI_MULADD = 0, 1, 2
+
+c_fp = ctypes.c_void_p
+
+
+class Conv1x1Desc(ctypes.Structure):
+    _fields_ = [
+        ("x", c_fp * 3), ("xbs", ctypes.c_long * 3), ("kseg", ctypes.c_int * 3),
+        ("w", c_fp), ("bias", c_fp), ("out", c_fp), ("obs", ctypes.c_long),
+        ("B", ctypes.c_int), ("K", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_int),
+        ("pro", ctypes.c_int), ("ln_group", ctypes.c_int),
+        ("stats", c_fp), ("gamma", c_fp), ("beta", c_fp), ("xb", c_fp), ("xbbs", ctypes.c_long),
+        ("act", ctypes.c_int), ("epi", ctypes.c_int),
+        ("res", c_fp), ("rbs", ctypes.c_long), ("mul", c_fp), ("add", c_fp), ("mbs", ctypes.c_long),
+        ("vec4", ctypes.c_int),
+    ]
+
+
+class FdnHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load libfdn_hip.so once.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} not found: build it with fdn-tip2025_amd/build.sh (hipcc --offload-arch=gfx950). "
+                "The FDN path has no CPU fallback.")
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.fdn_error_string.restype = ctypes.c_char_p
+        _lib.fdn_abi_version.restype = ctypes.c_int
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise FdnHipError(f"{what}: {lib().fdn_error_string(code).decode()} (code {code})")
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(t, what="tensor"):
+    """Validate a tensor handed to the library and return its device pointer."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise FdnHipError(f"{what} must live on a ROCm device (got {t.device}); the FDN path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise FdnHipError(f"{what} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise FdnHipError(f"{what} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+from . import ops  # noqa: E402,F401

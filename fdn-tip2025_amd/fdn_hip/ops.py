@@ -1,0 +1,144 @@
+"""Tensor-level wrappers around the C ABI (one Python function per entry point of fdn_hip.h).
+
+Inputs are fp32 ROCm tensors in NCHW layout.  A tensor argument may be a channel slice
+`t[:, a:b]` of a contiguous NCHW tensor (inner three dims dense, arbitrary batch stride).
+"""
+import ctypes
+
+import torch
+
+from . import (ACT_NONE, EPI_MULADD, EPI_NONE, EPI_RES, PRO_LN, PRO_LN3_GATE, PRO_LN_MULADD, PRO_NONE,
+               Conv1x1Desc, FdnHipError, check, lib, stream)
+
+
+def _planes(t, what):
+    """(device pointer, batch stride in elements) of an NCHW tensor whose C,H,W dims are dense."""
+    if not t.is_cuda:
+        raise FdnHipError(f"{what} must live on a ROCm device (got {t.device}); the FDN path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise FdnHipError(f"{what} must be float32 (got {t.dtype})")
+    assert t.dim() == 4, what
+    _, C, H, W = t.shape
+    st = t.stride()
+    if not (st[3] == 1 and st[2] == W and st[1] == H * W) and t.numel() > 0:
+        raise FdnHipError(f"{what}: channel/row/column dims must be dense (strides {st})")
+    return ctypes.c_void_p(t.data_ptr()), (st[0] if t.shape[0] > 1 else C * H * W)
+
+
+def _flat(t, what):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise FdnHipError(f"{what} must be a contiguous float32 ROCm tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None, ln_muladd=None, res=None,
+            muladd=None):
+    """1x1 conv with fused prologue/epilogue (fdn_conv1x1).
+
+    xs: tensor or list of <=3 tensors concatenated along channels.  w: [N, K] or [N, K, 1, 1].
+    ln=(stats, gamma, beta) | ln3_gate=(stats, gamma[3E], beta[3E], vv) | ln_muladd=(stats, gamma, beta, x1)
+    res: residual added after act | muladd=(mul, add).
+    """
+    if torch.is_tensor(xs):
+        xs = [xs]
+    B, _, H, W = xs[0].shape
+    P = H * W
+    N = w.shape[0]
+    K = sum(x.shape[1] for x in xs)
+    assert w.numel() == N * K, (w.shape, K)
+    if out is None:
+        out = torch.empty((B, N, H, W), device=xs[0].device, dtype=torch.float32)
+    d = Conv1x1Desc()
+    for i, x in enumerate(xs):
+        d.x[i], d.xbs[i] = _planes(x, f"x[{i}]")
+        d.kseg[i] = x.shape[1]
+    d.w = _flat(w, "w")
+    d.bias = _flat(bias, "bias")
+    d.out, d.obs = _planes(out, "out")
+    d.B, d.K, d.N, d.P = B, K, N, P
+    d.pro, d.ln_group = PRO_NONE, K
+    if ln is not None:
+        d.pro = PRO_LN
+        d.stats, d.gamma, d.beta = _flat(ln[0], "stats"), _flat(ln[1], "gamma"), _flat(ln[2], "beta")
+    elif ln3_gate is not None:
+        d.pro, d.ln_group = PRO_LN3_GATE, K // 3
+        d.stats, d.gamma, d.beta = _flat(ln3_gate[0], "stats"), _flat(ln3_gate[1], "gamma"), _flat(ln3_gate[2], "beta")
+        d.xb, d.xbbs = _planes(ln3_gate[3], "v_value")
+    elif ln_muladd is not None:
+        d.pro = PRO_LN_MULADD
+        d.stats, d.gamma, d.beta = _flat(ln_muladd[0], "stats"), _flat(ln_muladd[1], "gamma"), _flat(ln_muladd[2], "beta")
+        d.xb, d.xbbs = _planes(ln_muladd[3], "x1")
+    d.act = act
+    d.epi = EPI_NONE
+    if res is not None:
+        d.epi = EPI_RES
+        d.res, d.rbs = _planes(res, "res")
+    elif muladd is not None:
+        d.epi = EPI_MULADD
+        d.mul, d.mbs = _planes(muladd[0], "mul")
+        d.add, mbs2 = _planes(muladd[1], "add")
+        assert mbs2 == d.mbs
+    check(lib().fdn_conv1x1(ctypes.byref(d), stream()), "fdn_conv1x1")
+    return out
+
+
+def chan_stats(x, groups=1):
+    """(mean, rstd) over each of `groups` equal channel groups -> [B, G, 2, H*W] (fdn_chan_stats)."""
+    B, C, H, W = x.shape
+    E = C // groups
+    ptr, xbs = _planes(x, "x")
+    stats = torch.empty((B, groups, 2, H * W), device=x.device, dtype=torch.float32)
+    check(lib().fdn_chan_stats(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), B, groups, E, H * W, stream()),
+          "fdn_chan_stats")
+    return stats
+
+
+def layernorm_chan(x, gamma, beta):
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    check(lib().fdn_layernorm_chan(_flat(x, "x"), _flat(gamma, "gamma"), _flat(beta, "beta"), _flat(out, "out"),
+                                   B, C, H * W, stream()), "fdn_layernorm_chan")
+    return out
+
+
+def fdsa_core(hidden, dw_w, fft_w):
+    B, C4, H, W = hidden.shape
+    out = torch.empty_like(hidden)
+    check(lib().fdn_fdsa_core(_flat(hidden, "hidden"), _flat(dw_w, "dw_w"), _flat(fft_w, "fft_w"), _flat(out, "out"),
+                              B, C4 // 4, H, W, stream()), "fdn_fdsa_core")
+    return out
+
+
+def fdffn_mid(x, w0, w2, ffta, fftp):
+    B, Hd, H, W = x.shape
+    out = torch.empty_like(x)
+    check(lib().fdn_fdffn_mid(_flat(x, "x"), _flat(w0, "w0"), _flat(w2, "w2"), _flat(ffta, "ffta"), _flat(fftp, "fftp"),
+                              _flat(out, "out"), B, Hd, H, W, stream()), "fdn_fdffn_mid")
+    return out
+
+
+def dwconv_gate(x, w):
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    check(lib().fdn_dwconv_gate(_flat(x, "x"), _flat(w, "w"), _flat(out, "out"), B, C, H, W, stream()), "fdn_dwconv_gate")
+    return out
+
+
+def dwconv3x3(x, w, act=ACT_NONE):
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    check(lib().fdn_dwconv3x3(_flat(x, "x"), _flat(w, "w"), _flat(out, "out"), B, C, H, W, act, stream()), "fdn_dwconv3x3")
+    return out
+
+
+def img_mod_maps(img, w1_mul, w3_mul, w1_add, w3_add):
+    B, _, H, W = img.shape
+    C = w1_mul.shape[0]
+    mul = torch.empty((B, C, H, W), device=img.device, dtype=torch.float32)
+    add = torch.empty_like(mul)
+    check(lib().fdn_img_mod_maps(_flat(img, "img"), _flat(w1_mul, "w1_mul"), _flat(w3_mul, "w3_mul"),
+                                 _flat(w1_add, "w1_add"), _flat(w3_add, "w3_add"), _flat(mul, "mul"), _flat(add, "add"),
+                                 B, C, H, W, stream()), "fdn_img_mod_maps")
+    return mul, add
