@@ -1,0 +1,297 @@
+// Dense k x k convolutions, resampling and the small MAR / LPNet helpers of the FDN path.
+//   fdn_conv2d          : direct dense conv (any k, stride, pad; groups=1) with bias / residual /
+//                         activation epilogue: OverlapPatchEmbed, Downsample, Upsample, output conv
+//                         (FDN_arch.py:704,720,731,804), MAR's 3x3 / stride-2 convs (:57,:135,
+//                         :174-175,:192-193,:196), LPNet's 7x7 s2, 3x3 and strided 1x1 convs
+//                         (LPNet_arch.py:49-62,:91)
+//   fdn_conv_transpose4x4s2 : ConvTranspose2d(k=4,s=2,p=1) + LeakyReLU (FDN_arch.py:21-23,:194-195)
+//   fdn_resample        : bilinear 1/2 and x2 (align_corners=False), nearest 1/2 and x2,
+//                         PixelUnshuffle (FDN_arch.py:199-206,:230-233,:719,:730,:866)
+// Thread = one output pixel (lanes contiguous along W), OCB output channels in registers; the
+// weight address is wave-uniform so it rides the scalar cache.
+#include "common.hpp"
+
+namespace {
+
+constexpr int OCB = 8;
+
+struct ConvArgs {
+    const float* x; const float* w; const float* bias; const float* res; float* out;
+    int B, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad;
+    int act; int res_before_act; float post_add;
+};
+
+__global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
+    const long op = (long)blockIdx.x * 256 + threadIdx.x;
+    const int oc0 = blockIdx.y * OCB, b = blockIdx.z;
+    const long OP = (long)a.OH * a.OW;
+    const bool live = op < OP;
+    const int oy = live ? (int)(op / a.OW) : 0, ox = live ? (int)(op - (long)oy * a.OW) : 0;
+    float acc[OCB];
+#pragma unroll
+    for (int o = 0; o < OCB; ++o) acc[o] = 0.f;
+    const int nvalid = min(OCB, a.Cout - oc0);
+    const long hw = (long)a.H * a.W;
+    const int kk = a.KH * a.KW;
+    const float* xb = a.x + (long)b * a.Cin * hw;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float* xc = xb + (long)ci * hw;
+        for (int ky = 0; ky < a.KH; ++ky) {
+            const int iy = oy * a.stride - a.pad + ky;
+            const bool yok = iy >= 0 && iy < a.H;
+            for (int kx = 0; kx < a.KW; ++kx) {
+                const int ix = ox * a.stride - a.pad + kx;
+                const float v = (live && yok && ix >= 0 && ix < a.W) ? xc[(long)iy * a.W + ix] : 0.f;
+                const float* wp = a.w + ((long)oc0 * a.Cin + ci) * kk + ky * a.KW + kx;
+#pragma unroll
+                for (int o = 0; o < OCB; ++o)
+                    if (o < nvalid) acc[o] = fmaf(v, wp[(long)o * a.Cin * kk], acc[o]);
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int o = 0; o < OCB; ++o) {
+        if (o >= nvalid) break;
+        const int oc = oc0 + o;
+        float v = acc[o] + (a.bias ? a.bias[oc] : 0.f);
+        const long oi = ((long)b * a.Cout + oc) * OP + op;
+        if (a.res && a.res_before_act) v += a.res[oi];
+        v = apply_act(v, a.act);
+        if (a.res && !a.res_before_act) v += a.res[oi];
+        a.out[oi] = v + a.post_add;
+    }
+}
+
+// ConvTranspose2d(Cin, Cout, 4, stride 2, padding 1): weight [Cin][Cout][4][4]; OH = 2H, OW = 2W
+__global__ __launch_bounds__(256) void convT_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int Cin, int H,
+                                                    int W, int Cout, int act) {
+    const int OH = 2 * H, OW = 2 * W;
+    const long op = (long)blockIdx.x * 256 + threadIdx.x;
+    const int oc0 = blockIdx.y * OCB, b = blockIdx.z;
+    const long OP = (long)OH * OW;
+    const bool live = op < OP;
+    const int oy = live ? (int)(op / OW) : 0, ox = live ? (int)(op - (long)oy * OW) : 0;
+    const int nvalid = min(OCB, Cout - oc0);
+    float acc[OCB];
+#pragma unroll
+    for (int o = 0; o < OCB; ++o) acc[o] = 0.f;
+    const long hw = (long)H * W;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xc = x + ((long)b * Cin + ci) * hw;
+        for (int ky = 0; ky < 4; ++ky) {
+            const int ty = oy + 1 - ky;                 // = 2*iy
+            const bool yok = ty >= 0 && (ty & 1) == 0 && (ty >> 1) < H;
+            for (int kx = 0; kx < 4; ++kx) {
+                const int tx = ox + 1 - kx;
+                const bool ok = live && yok && tx >= 0 && (tx & 1) == 0 && (tx >> 1) < W;
+                const float v = ok ? xc[(long)(ty >> 1) * W + (tx >> 1)] : 0.f;
+                const float* wp = w + ((long)ci * Cout + oc0) * 16 + ky * 4 + kx;
+#pragma unroll
+                for (int o = 0; o < OCB; ++o)
+                    if (o < nvalid) acc[o] = fmaf(v, wp[o * 16], acc[o]);
+            }
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int o = 0; o < OCB; ++o) {
+        if (o >= nvalid) break;
+        out[((long)b * Cout + oc0 + o) * OP + op] = apply_act(acc[o] + (bias ? bias[oc0 + o] : 0.f), act);
+    }
+}
+
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, float* __restrict__ out, long planes, int H,
+                                                       int W, int OH, int OW, int mode, int r) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = planes * OH * OW;
+    if (idx >= total) return;
+    const int ox = (int)(idx % OW);
+    const long t = idx / OW;
+    const int oy = (int)(t % OH);
+    const long pl = t / OH;
+    if (mode == FDN_RS_BILINEAR_HALF) {
+        const float* s = x + pl * H * W + (long)(2 * oy) * W + 2 * ox;
+        // area_pixel source index 2*o+0.5: lambda = 0.5 on both axes (exact 2x2 mean)
+        out[idx] = 0.5f * (0.5f * s[0] + 0.5f * s[1]) + 0.5f * (0.5f * s[W] + 0.5f * s[W + 1]);
+    } else if (mode == FDN_RS_BILINEAR_X2) {
+        float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - y0, lx = sx - x0;
+        const float* s = x + pl * H * W;
+        out[idx] = (1.f - ly) * ((1.f - lx) * s[(long)y0 * W + x0] + lx * s[(long)y0 * W + x1]) +
+                   ly * ((1.f - lx) * s[(long)y1 * W + x0] + lx * s[(long)y1 * W + x1]);
+    } else if (mode == FDN_RS_NEAREST_HALF) {
+        out[idx] = x[pl * H * W + (long)(2 * oy) * W + 2 * ox];
+    } else if (mode == FDN_RS_NEAREST_X2) {
+        out[idx] = x[pl * H * W + (long)(oy >> 1) * W + (ox >> 1)];
+    } else {  // PixelUnshuffle(r): out plane = (b*C + c)*r*r + i*r + j ; planes counts output planes
+        const long inpl = pl / (r * r);
+        const int ij = (int)(pl - inpl * r * r);
+        const int i = ij / r, j = ij - i * r;
+        out[idx] = x[inpl * H * W + (long)(oy * r + i) * W + ox * r + j];
+    }
+}
+
+// fourier_fuse.fpre[1]: Conv2d(n, n, 1, padding=1, groups=n): (H+2)x(W+2) map, bias-only border
+__global__ __launch_bounds__(256) void dw1x1_pad1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int C, int H,
+                                                         int W, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int OW = W + 2, OH = H + 2;
+    const int ox = (int)(idx % OW);
+    const long t = idx / OW;
+    const int oy = (int)(t % OH);
+    const long pl = t / OH;
+    const int c = (int)(pl % C);
+    const bool in = oy >= 1 && oy <= H && ox >= 1 && ox <= W;
+    out[idx] = (in ? w[c] * x[pl * H * W + (long)(oy - 1) * W + ox - 1] : 0.f) + bias[c];
+}
+
+// AvgPool2d(3, stride 2, padding 1), count_include_pad=True (LPNet_arch.py:94)
+__global__ __launch_bounds__(256) void avgpool3s2_kernel(const float* __restrict__ x, float* __restrict__ out, long planes,
+                                                         int H, int W, int OH, int OW) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * OH * OW) return;
+    const int ox = (int)(idx % OW);
+    const long t = idx / OW;
+    const int oy = (int)(t % OH);
+    const float* s = x + (t / OH) * H * W;
+    float a = 0.f;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int y = 2 * oy + dy, xx = 2 * ox + dx;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) a += s[(long)y * W + xx];
+        }
+    out[idx] = a / 9.0f;
+}
+
+// mean over H*W of each plane (AdaptiveAvgPool2d(1)); one workgroup per plane
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ out, long P) {
+    __shared__ float red[256];
+    const float* s = x + (long)blockIdx.x * P;
+    float a = 0.f;
+    for (long i = threadIdx.x; i < P; i += 256) a += s[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] / (float)P;
+}
+
+// SE tail: relu(y * gate[plane] + shortcut)  (LPNet_arch.py:75-80)
+__global__ __launch_bounds__(256) void se_apply_kernel(const float* __restrict__ y, const float* __restrict__ gate,
+                                                       const float* __restrict__ sc, float* __restrict__ out, long P,
+                                                       long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    out[idx] = fmaxf(fmaf(y[idx], gate[idx / P], sc[idx]), 0.f);
+}
+
+// x *= ratio[b]   (MAR_archa.forward, FDN_arch.py:213-219)
+__global__ __launch_bounds__(256) void scale_batch_kernel(float* __restrict__ x, const float* __restrict__ ratio, long per_b,
+                                                          long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < total) x[idx] *= ratio[idx / per_b];
+}
+
+// gamma curve 1 - (1 - x)^(40 * i)   (MAR.forward, FDN_arch.py:282-284)
+__global__ __launch_bounds__(256) void gamma_curve_kernel(const float* __restrict__ x, const float* __restrict__ im,
+                                                          float* __restrict__ out, float scale, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < total) out[idx] = 1.0f - powf(1.0f - x[idx], im[idx] * scale);
+}
+
+}  // namespace
+
+extern "C" int fdn_conv2d(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int Cin,
+                          int H, int W, int Cout, int KH, int KW, int stride, int pad, int act, int res_before_act,
+                          float post_add, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out;
+    a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.OH = (H + 2 * pad - KH) / stride + 1;
+    a.OW = (W + 2 * pad - KW) / stride + 1;
+    FDN_CHECK_ARG(a.OH > 0 && a.OW > 0);
+    a.act = act; a.res_before_act = res_before_act; a.post_add = post_add;
+    hipLaunchKernelGGL(conv2d_kernel, dim3(cdiv((long)a.OH * a.OW, 256), cdiv(Cout, OCB), B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_conv_transpose4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H,
+                                       int W, int Cout, int act, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
+    hipLaunchKernelGGL(convT_kernel, dim3(cdiv(4L * H * W, 256), cdiv(Cout, OCB), B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, w, bias, out, Cin, H, W, Cout, act);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_resample(const float* x, float* out, long planes, int H, int W, int mode, int r, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && out && planes > 0 && H > 0 && W > 0);
+    int OH, OW;
+    long oplanes = planes;
+    switch (mode) {
+        case FDN_RS_BILINEAR_HALF:
+        case FDN_RS_NEAREST_HALF: FDN_CHECK_ARG(H % 2 == 0 && W % 2 == 0); OH = H / 2; OW = W / 2; break;
+        case FDN_RS_BILINEAR_X2:
+        case FDN_RS_NEAREST_X2: OH = 2 * H; OW = 2 * W; break;
+        case FDN_RS_PIXEL_UNSHUFFLE: FDN_CHECK_ARG(r > 0 && H % r == 0 && W % r == 0); OH = H / r; OW = W / r; oplanes = planes * r * r; break;
+        default: return FDN_ERR_ARG;
+    }
+    const long total = oplanes * OH * OW;
+    hipLaunchKernelGGL(resample_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, oplanes,
+                       H, W, OH, OW, mode, r);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_dw1x1_pad1(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int W,
+                              fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && w && bias && out && B > 0 && C > 0 && H > 0 && W > 0);
+    const long total = (long)B * C * (H + 2) * (W + 2);
+    hipLaunchKernelGGL(dw1x1_pad1_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, bias, out,
+                       C, H, W, total);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_avgpool3s2(const float* x, float* out, long planes, int H, int W, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && out && planes > 0 && H > 0 && W > 0);
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(avgpool3s2_kernel, dim3(cdiv(planes * OH * OW, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       out, planes, H, W, OH, OW);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_global_avgpool(const float* x, float* out, long planes, long P, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && out && planes > 0 && P > 0);
+    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)planes), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, P);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_se_apply(const float* y, const float* gate, const float* shortcut, float* out, long planes, long P,
+                            fdn_stream_t stream) {
+    FDN_CHECK_ARG(y && gate && shortcut && out && planes > 0 && P > 0);
+    hipLaunchKernelGGL(se_apply_kernel, dim3(cdiv(planes * P, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), y, gate,
+                       shortcut, out, P, planes * P);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_scale_batch(float* x, const float* ratio, int B, long per_batch, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && ratio && B > 0 && per_batch > 0);
+    hipLaunchKernelGGL(scale_batch_kernel, dim3(cdiv(B * per_batch, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       ratio, per_batch, B * per_batch);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_gamma_curve(const float* x, const float* i_map, float* out, float scale, long total, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && i_map && out && total > 0);
+    hipLaunchKernelGGL(gamma_curve_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, i_map, out,
+                       scale, total);
+    return fdn_launch_status();
+}

@@ -1,0 +1,470 @@
+// Full-image real 2-D FFT pipeline (norm='backward') for FCAFFN, the FDN guidance transforms and
+// MAR (FDN_arch.py:90-98, :139-147, :411-418, :882-914): mixed-radix Stockham autosort FFTs staged
+// in LDS, any length (720p needs radices 2/4/5/23, 1080p 3/5/17, fourier_fuse 41/641/...).
+//
+//   rows   : real row of length W -> half-length complex FFT (M = W/2) + split post-pass -> W/2+1 bins
+//   columns: a workgroup owns TC adjacent columns x all H rows of one (b,c) plane in LDS, runs the
+//            forward FFT, the pointwise spectral op and (FCAFFN) the inverse FFT without leaving
+//            the CU: FFT <-> pointwise <-> iFFT fused in one launch
+//   rows^-1: Hermitian merge pre-pass + half-length inverse FFT -> real row (+ residual epilogue)
+//
+// A Stockham pass of radix R maps N/R butterflies onto the threads; radix 2 and 4 are register
+// butterflies, every other prime uses the gather form out[m] = sum_r in[i + r*N/R] * W_L^{r*m}.
+// Twiddles come from one immutable table W_N^t per length, built on first use with exact
+// values on the axes (so DC/Nyquist bins of real data stay exactly real).
+#include <math.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAX_STAGES = 16;
+constexpr int NT = 256;
+
+struct Plan {
+    int N;                     // transform length
+    int nst;
+    int radix[MAX_STAGES];
+    const float2* tw;          // W_tabN^t, t in [0, tabN)
+    int tab_mul;               // tabN / N
+};
+
+// ------------------------------------------------------------------------------------------
+// host: plan cache
+// ------------------------------------------------------------------------------------------
+std::mutex g_mu;
+std::map<std::pair<int, int>, const float2*> g_tables;   // (device, N) -> device table
+
+const float2* get_table(int N) {
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_tables.find({devid, N});
+    if (it != g_tables.end()) return it->second;
+    std::vector<float2> h(N);
+    for (int t = 0; t < N; ++t) {
+        double c, s;
+        if ((4L * t) % N == 0) {                      // exact on the axes
+            const int q = (int)((4L * t) / N);        // quarter turns
+            c = (q == 0) ? 1.0 : (q == 2 ? -1.0 : 0.0);
+            s = (q == 1) ? 1.0 : (q == 3 ? -1.0 : 0.0);
+        } else {
+            const double a = 2.0 * M_PI * (double)t / (double)N;
+            c = cos(a);
+            s = sin(a);
+        }
+        h[t] = make_float2((float)c, (float)(-s) + 0.0f);   // e^{-2 pi i t / N}; "+0" keeps zeros positive
+        if (h[t].y == 0.0f) h[t].y = 0.0f;
+        if (h[t].x == 0.0f) h[t].x = 0.0f;
+    }
+    float2* d = nullptr;
+    if (hipMalloc(&d, sizeof(float2) * N) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), sizeof(float2) * N, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    g_tables[{devid, N}] = d;
+    return d;
+}
+
+bool make_plan(int N, int tabN, Plan* p) {
+    p->N = N;
+    p->nst = 0;
+    int n = N;
+    auto push = [&](int r) { if (p->nst < MAX_STAGES) p->radix[p->nst++] = r; };
+    while (n % 4 == 0) { push(4); n /= 4; }
+    while (n % 2 == 0) { push(2); n /= 2; }
+    for (int f = 3; (long)f * f <= n; f += 2)
+        while (n % f == 0) { push(f); n /= f; }
+    if (n > 1) push(n);
+    int prod = 1;
+    for (int i = 0; i < p->nst; ++i) prod *= p->radix[i];
+    if (prod != N || tabN % N != 0) return false;
+    p->tw = get_table(tabN);
+    p->tab_mul = tabN / N;
+    return p->tw != nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// device: Stockham passes over sequences held in LDS
+//   element idx of sequence s lives at  s*ss + idx*es
+// ------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ float2 twd(const float2* __restrict__ tw, int idx) {
+    const float2 w = tw[idx];
+    return INV ? make_float2(w.x, -w.y) : w;
+}
+
+template <bool INV>
+__device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, int nseq, int ss, int es, bool seq_fast,
+                         const float2* __restrict__ tw, int tab_mul) {
+    const int T = N / R;
+    const int L = Ns * R;
+    const int tws = tab_mul * (N / L);        // W_L^e = tw[e * tws]
+    const int jobs = T * nseq;
+    if (R != 2 && R != 4) {
+        // gather form, one output element per job: out[m] = sum_r in[i + r*T] * W_L^{r*m}
+        const int jobs2 = jobs * R;
+        for (int job2 = threadIdx.x; job2 < jobs2; job2 += NT) {
+            const int o = job2 / jobs, job = job2 - o * jobs;
+            int i, s;
+            if (seq_fast) { i = job / nseq; s = job - i * nseq; }
+            else { s = job / T; i = job - s * T; }
+            const int k = i % Ns;
+            const int j = (i - k) * R + k;
+            const float2* sp = src + s * ss;
+            const int m = k + o * Ns;              // output position inside the length-L block
+            float2 acc = sp[i * es];
+            int e = 0;
+            for (int r = 1; r < R; ++r) {
+                e += m;
+                if (e >= L) e -= L;
+                const float2 w = twd<INV>(tw, e * tws);
+                const float2 v = sp[(i + r * T) * es];
+                acc.x = fmaf(v.x, w.x, fmaf(-v.y, w.y, acc.x));
+                acc.y = fmaf(v.x, w.y, fmaf(v.y, w.x, acc.y));
+            }
+            dst[s * ss + (j + o * Ns) * es] = acc;
+        }
+        return;
+    }
+    for (int job = threadIdx.x; job < jobs; job += NT) {
+        int i, s;
+        if (seq_fast) { i = job / nseq; s = job - i * nseq; }
+        else { s = job / T; i = job - s * T; }
+        const int k = i % Ns;
+        const int j = (i - k) * R + k;
+        const float2* sp = src + s * ss;
+        float2* dp = dst + s * ss;
+        if (R == 4) {
+            float2 u0 = sp[i * es];
+            float2 u1 = sp[(i + T) * es], u2 = sp[(i + 2 * T) * es], u3 = sp[(i + 3 * T) * es];
+            if (k) {
+                u1 = cmul(u1, twd<INV>(tw, k * tws));
+                u2 = cmul(u2, twd<INV>(tw, 2 * k * tws));
+                u3 = cmul(u3, twd<INV>(tw, 3 * k * tws));
+            }
+            const float2 a = make_float2(u0.x + u2.x, u0.y + u2.y), b = make_float2(u0.x - u2.x, u0.y - u2.y);
+            const float2 c = make_float2(u1.x + u3.x, u1.y + u3.y), d = make_float2(u1.x - u3.x, u1.y - u3.y);
+            // forward: -i*d = (d.y, -d.x) ; inverse: +i*d = (-d.y, d.x)
+            const float2 jd = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+            dp[j * es] = make_float2(a.x + c.x, a.y + c.y);
+            dp[(j + Ns) * es] = make_float2(b.x + jd.x, b.y + jd.y);
+            dp[(j + 2 * Ns) * es] = make_float2(a.x - c.x, a.y - c.y);
+            dp[(j + 3 * Ns) * es] = make_float2(b.x - jd.x, b.y - jd.y);
+        } else {
+            const float2 u0 = sp[i * es];
+            float2 u1 = sp[(i + T) * es];
+            if (k) u1 = cmul(u1, twd<INV>(tw, k * tws));
+            dp[j * es] = make_float2(u0.x + u1.x, u0.y + u1.y);
+            dp[(j + Ns) * es] = make_float2(u0.x - u1.x, u0.y - u1.y);
+        }
+    }
+}
+
+// run all passes; returns the buffer holding the result
+template <bool INV>
+__device__ float2* fft_run(float2* a, float2* b, const Plan& p, int nseq, int ss, int es, bool seq_fast) {
+    int Ns = 1;
+    float2* src = a;
+    float2* dst = b;
+    for (int st = 0; st < p.nst; ++st) {
+        __syncthreads();
+        fft_pass<INV>(src, dst, p.N, Ns, p.radix[st], nseq, ss, es, seq_fast, p.tw, p.tab_mul);
+        Ns *= p.radix[st];
+        float2* t = src; src = dst; dst = t;
+    }
+    __syncthreads();
+    return src;
+}
+
+// ------------------------------------------------------------------------------------------
+// rows: r2c
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__ in, float2* __restrict__ out, int W, long R,
+                                                       int rpb, Plan p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = W / 2, Wf = M + 1;
+    float2* A = reinterpret_cast<float2*>(smem);
+    float2* Bf = A + (long)rpb * M;
+    const long row0 = (long)blockIdx.x * rpb;
+    const int nrow = (int)min((long)rpb, R - row0);
+    for (int idx = threadIdx.x; idx < rpb * M; idx += NT) {
+        const int s = idx / M, m = idx - s * M;
+        A[idx] = (s < nrow) ? reinterpret_cast<const float2*>(in + (row0 + s) * W)[m] : make_float2(0.f, 0.f);
+    }
+    float2* Z = fft_run<false>(A, Bf, p, rpb, M, 1, false);
+    // split: X[k] = E[k] + W_N^k O[k],  E = (Z[k]+conj Z[M-k])/2,  O = -i (Z[k]-conj Z[M-k])/2
+    const int tw1 = p.tab_mul / 2;              // table is W_W^t:  tab_mul = W / M = 2  -> stride 1
+    for (int idx = threadIdx.x; idx < nrow * Wf; idx += NT) {
+        const int s = idx / Wf, k = idx - s * Wf;
+        const float2 zk = Z[s * M + (k == M ? 0 : k)];
+        const float2 zc = Z[s * M + (k == 0 ? 0 : M - k)];
+        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        const float2 d = make_float2(0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y));   // (Z - conj Zc)/2
+        const float2 o = make_float2(d.y, -d.x);                                     // -i * d
+        float2 x;
+        if (k == 0) x = make_float2(e.x + o.x, 0.0f);
+        else if (k == M) x = make_float2(e.x - o.x, 0.0f);
+        else {
+            const float2 w = p.tw[k * tw1];
+            x = make_float2(e.x + (o.x * w.x - o.y * w.y), e.y + (o.x * w.y + o.y * w.x));
+        }
+        out[(row0 + s) * Wf + k] = x;
+    }
+}
+
+// rows: c2r.  in rows have stride in_ws bins (>= M+1: leading-slice crop of a wider spectrum)
+__global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict__ in, long in_ws, long in_plane_rows,
+                                                        long in_plane_stride, float* __restrict__ out, int W, int H, long R,
+                                                        int rpb, float scale, const float* __restrict__ res, float alpha,
+                                                        Plan p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int M = W / 2;
+    float2* A = reinterpret_cast<float2*>(smem);
+    float2* Bf = A + (long)rpb * M;
+    const long row0 = (long)blockIdx.x * rpb;
+    const int nrow = (int)min((long)rpb, R - row0);
+    const int tw1 = p.tab_mul / 2;
+    for (int idx = threadIdx.x; idx < rpb * M; idx += NT) {
+        const int s = idx / M, k = idx - s * M;
+        float2 z = make_float2(0.f, 0.f);
+        if (s < nrow) {
+            const long row = row0 + s;
+            const long plane = row / H, h = row - plane * H;
+            const float2* src = in + plane * in_plane_stride + h * in_ws;
+            float2 xk = src[k], xc = src[M - k];
+            if (k == 0) { xk.y = 0.f; xc.y = 0.f; }            // c2r ignores Im of DC and Nyquist
+            // E = (X[k] + conj X[M-k])/2 ; O = (X[k] - conj X[M-k])/2 * W_N^{-k} ; Z = E + i O
+            const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));
+            const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y + xc.y));
+            const float2 w = p.tw[k * tw1];                     // conj -> W^{-k}
+            const float2 o = make_float2(d.x * w.x + d.y * w.y, d.y * w.x - d.x * w.y);
+            z = make_float2(e.x - o.y, e.y + o.x);
+        }
+        A[idx] = z;
+    }
+    float2* Z = fft_run<true>(A, Bf, p, rpb, M, 1, false);
+    for (int idx = threadIdx.x; idx < nrow * M; idx += NT) {
+        const int s = idx / M, m = idx - s * M;
+        const long row = row0 + s;
+        float2 v = Z[idx];
+        v.x *= scale;
+        v.y *= scale;
+        if (res) {
+            const float2 r = reinterpret_cast<const float2*>(res + row * W)[m];
+            v.x = fmaf(alpha, r.x, v.x);
+            v.y = fmaf(alpha, r.y, v.y);
+        }
+        reinterpret_cast<float2*>(out + row * W)[m] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// columns
+// ------------------------------------------------------------------------------------------
+struct ColArgs {
+    // spectrum planes: [planes][H][Wf] complex
+    float2* z;                 // in/out (FCAFFN), in (fwd), out (inv polar)
+    int H, Wf, C;              // C = channels per batch item (plane = b*C + c)
+    int tc;
+    // FCAFFN modulation (FDN_arch.py:412-417)
+    const float* amp;          // [B][3][H][Wf]
+    const float* pha;          // [B][3][H][Wf]
+    const float* wxa;          // [C][3]
+    const float* wxp;          // [C][3]
+    // forward outputs (real planes [planes][H][Wf])
+    float* out_abs;
+    float* out_ang;
+    int rd_before;             // replace_denormals before abs/angle
+    int fix_real;              // force Im = +0 at the self-conjugate bins of a real transform
+    // inverse-from-polar inputs: planes [planes][Hin][Wfin], leading (H, Wf) slice used
+    const float* in_mag;
+    const float* in_pha;
+    int Hin, Wfin;
+};
+
+enum { COL_FCAFFN = 0, COL_FWD = 1, COL_INV_POLAR = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(NT) void fft_cols_kernel(ColArgs a, Plan p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = a.H, Wf = a.Wf, tc = a.tc;
+    float2* A = reinterpret_cast<float2*>(smem);
+    float2* Bf = A + (long)H * tc;
+    const int plane = blockIdx.y;
+    const int col0 = blockIdx.x * tc;
+    const int ncol = min(tc, Wf - col0);
+    float2* zp = a.z + (long)plane * H * Wf;
+
+    // ---- load --------------------------------------------------------------------------------
+    for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
+        const int h = idx / tc, c = idx - h * tc;
+        float2 v = make_float2(0.f, 0.f);
+        if (c < ncol) {
+            if (MODE == COL_INV_POLAR) {
+                const long o = ((long)plane * a.Hin + h) * a.Wfin + col0 + c;
+                const float m = a.in_mag[o], ph = a.in_pha[o];
+                float sn, cs;
+                sincosf(ph, &sn, &cs);
+                v = make_float2(m * cs, m * sn);                                  // FDN_arch.py:95-97
+            } else {
+                v = zp[(long)h * Wf + col0 + c];
+            }
+        }
+        A[idx] = v;
+    }
+    float2* Z = A;
+    if (MODE != COL_INV_POLAR) Z = fft_run<false>(A, Bf, p, tc, 1, tc, true);
+    float2* other = (Z == A) ? Bf : A;
+
+    if (MODE == COL_FWD) {
+        const bool evenH = (H % 2) == 0;
+        for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
+            const int h = idx / tc, c = idx - h * tc;
+            if (c >= ncol) continue;
+            float2 v = Z[idx];
+            const int col = col0 + c;
+            if (a.fix_real && (col == 0 || col == Wf - 1) && (h == 0 || (evenH && h == H / 2))) v.y = 0.0f;
+            if (a.rd_before) v = make_float2(rd1(v.x), rd1(v.y));
+            const long o = ((long)plane * H + h) * Wf + col;
+            if (a.out_abs) a.out_abs[o] = cabs2(v);
+            if (a.out_ang) a.out_ang[o] = atan2f(v.y, v.x);
+        }
+        return;
+    }
+
+    if (MODE == COL_FCAFFN) {
+        const int b = plane / a.C, ch = plane - b * a.C;
+        const float wa0 = a.wxa[ch * 3], wa1 = a.wxa[ch * 3 + 1], wa2 = a.wxa[ch * 3 + 2];
+        const float wp0 = a.wxp[ch * 3], wp1 = a.wxp[ch * 3 + 1], wp2 = a.wxp[ch * 3 + 2];
+        const long gs = (long)H * Wf;
+        const float* ampb = a.amp + (long)b * 3 * gs;
+        const float* phab = a.pha + (long)b * 3 * gs;
+        for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
+            const int h = idx / tc, c = idx - h * tc;
+            if (c >= ncol) continue;
+            const long o = (long)h * Wf + col0 + c;
+            const float A_ = wa0 * ampb[o] + wa1 * ampb[gs + o] + wa2 * ampb[2 * gs + o];      // conv1_xa(x_high)
+            const float ph = wp0 * phab[o] + wp1 * phab[gs + o] + wp2 * phab[2 * gs + o];      // conv1_xp(xp2)
+            float sn, cs;
+            sincosf(ph, &sn, &cs);
+            const float2 v = Z[idx];
+            const float2 r = make_float2(rd1(v.x), rd1(v.y));                                   // :412
+            Z[idx] = cmul(r, make_float2(A_ * cs, -A_ * sn));           // |z| A e^{i(ang z - ph)}  :413-417
+        }
+    }
+    float2* Y = fft_run<true>(Z, other, p, tc, 1, tc, true);
+    for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
+        const int h = idx / tc, c = idx - h * tc;
+        if (c < ncol) zp[(long)h * Wf + col0 + c] = Y[idx];
+    }
+}
+
+int pick_tc(int H) {
+    const long per_col = 2L * H * sizeof(float2);
+    if (per_col * 16 <= 64 * 1024) return 16;
+    if (per_col * 8 <= 150 * 1024) return 8;
+    if (per_col * 4 <= 150 * 1024) return 4;
+    if (per_col * 2 <= 150 * 1024) return 2;
+    return 0;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
+            hipSuccess)
+            return FDN_ERR_LAUNCH;
+    }
+    return FDN_OK;
+}
+
+int pick_rpb(int M) {
+    int rpb = (int)((48 * 1024) / (2L * M * sizeof(float2)));
+    if (rpb > 8) rpb = 8;
+    if (rpb < 1) rpb = 1;
+    return rpb;
+}
+
+template <int MODE>
+int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
+    Plan p;
+    if (!make_plan(a.H, a.H, &p)) return FDN_ERR_UNSUPPORTED;
+    a.tc = pick_tc(a.H);
+    if (a.tc == 0 || planes > 65535 * 32L) return FDN_ERR_UNSUPPORTED;
+    const size_t lds = 2UL * a.H * a.tc * sizeof(float2);
+    if (int e = set_lds(fft_cols_kernel<MODE>, lds)) return e;
+    // planes on grid.y (<= 65535): fold if needed
+    if (planes > 65535) return FDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fft_cols_kernel<MODE>, dim3(cdiv(a.Wf, a.tc), (unsigned)planes), dim3(NT), lds,
+                       static_cast<hipStream_t>(stream), a, p);
+    return fdn_launch_status();
+}
+
+}  // namespace
+
+extern "C" int fdn_fft_prepare(int n) {
+    FDN_CHECK_ARG(n > 0);
+    return get_table(n) ? FDN_OK : FDN_ERR_LAUNCH;
+}
+
+extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t stream) {
+    FDN_CHECK_ARG(in && out_c && rows > 0 && W >= 2 && W % 2 == 0);
+    Plan p;
+    if (!make_plan(W / 2, W, &p)) return FDN_ERR_UNSUPPORTED;
+    const int rpb = pick_rpb(W / 2);
+    const size_t lds = 2UL * rpb * (W / 2) * sizeof(float2);
+    if (lds > 160 * 1024) return FDN_ERR_UNSUPPORTED;
+    if (int e = set_lds(rfft_rows_kernel, lds)) return e;
+    hipLaunchKernelGGL(rfft_rows_kernel, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream), in,
+                       reinterpret_cast<float2*>(out_c), W, rows, rpb, p);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane_bins, float* out, long planes, int H, int W,
+                              float scale, const float* res, float alpha, fdn_stream_t stream) {
+    FDN_CHECK_ARG(in_c && out && planes > 0 && H > 0 && W >= 2 && W % 2 == 0 && in_row_bins >= W / 2 + 1);
+    Plan p;
+    if (!make_plan(W / 2, W, &p)) return FDN_ERR_UNSUPPORTED;
+    const int rpb = pick_rpb(W / 2);
+    const size_t lds = 2UL * rpb * (W / 2) * sizeof(float2);
+    if (lds > 160 * 1024) return FDN_ERR_UNSUPPORTED;
+    if (int e = set_lds(irfft_rows_kernel, lds)) return e;
+    const long rows = planes * H;
+    hipLaunchKernelGGL(irfft_rows_kernel, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float2*>(in_c), in_row_bins, (long)H, in_plane_bins, out, W, H, rows, rpb, scale,
+                       res, alpha, p);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_fft_cols_fcaffn(float* z, const float* amp, const float* pha, const float* wxa, const float* wxp, int B,
+                                   int C, int H, int Wf, fdn_stream_t stream) {
+    FDN_CHECK_ARG(z && amp && pha && wxa && wxp && B > 0 && C > 0 && H > 0 && Wf > 0);
+    ColArgs a = {};
+    a.z = reinterpret_cast<float2*>(z);
+    a.H = H; a.Wf = Wf; a.C = C;
+    a.amp = amp; a.pha = pha; a.wxa = wxa; a.wxp = wxp;
+    return launch_cols<COL_FCAFFN>(a, (long)B * C, stream);
+}
+
+extern "C" int fdn_fft_cols_fwd(const float* z, float* out_abs, float* out_ang, long planes, int H, int Wf, int rd_before,
+                                int fix_real, fdn_stream_t stream) {
+    FDN_CHECK_ARG(z && (out_abs || out_ang) && planes > 0 && H > 0 && Wf > 0);
+    ColArgs a = {};
+    a.z = reinterpret_cast<float2*>(const_cast<float*>(z));
+    a.H = H; a.Wf = Wf; a.C = 1;
+    a.out_abs = out_abs; a.out_ang = out_ang; a.rd_before = rd_before; a.fix_real = fix_real;
+    return launch_cols<COL_FWD>(a, planes, stream);
+}
+
+extern "C" int fdn_fft_cols_inv_polar(const float* mag, const float* pha, int Hin, int Wfin, float* z_out, long planes, int H,
+                                      int Wf, fdn_stream_t stream) {
+    FDN_CHECK_ARG(mag && pha && z_out && planes > 0 && H > 0 && Wf > 0 && Hin >= H && Wfin >= Wf);
+    ColArgs a = {};
+    a.z = reinterpret_cast<float2*>(z_out);
+    a.H = H; a.Wf = Wf; a.C = 1;
+    a.in_mag = mag; a.in_pha = pha; a.Hin = Hin; a.Wfin = Wfin;
+    return launch_cols<COL_INV_POLAR>(a, planes, stream);
+}

@@ -142,3 +142,135 @@ def img_mod_maps(img, w1_mul, w3_mul, w1_add, w3_add):
                                  _flat(w1_add, "w1_add"), _flat(w3_add, "w3_add"), _flat(mul, "mul"), _flat(add, "add"),
                                  B, C, H, W, stream()), "fdn_img_mod_maps")
     return mul, add
+
+
+# ---------------------------------------------------------------------------------------------
+# full-image FFT pipeline
+# ---------------------------------------------------------------------------------------------
+RS_BILINEAR_HALF, RS_BILINEAR_X2, RS_NEAREST_HALF, RS_NEAREST_X2, RS_PIXEL_UNSHUFFLE = 0, 1, 2, 3, 4
+
+
+def rfft_rows(x):
+    """real [..., H, W] -> interleaved complex [..., H, W//2+1, 2] along the last axis."""
+    W = x.shape[-1]
+    rows = x.numel() // W
+    out = torch.empty(x.shape[:-1] + (W // 2 + 1, 2), device=x.device, dtype=torch.float32)
+    check(lib().fdn_rfft_rows(_flat(x, "x"), _flat(out, "out"), ctypes.c_long(rows), W, stream()), "fdn_rfft_rows")
+    return out
+
+
+def irfft_rows(z, H, W, scale, res=None, alpha=0.0, out=None):
+    """complex planes [B, C, Hin>=H, Wfin>=W//2+1, 2] -> real [B, C, H, W] = scale*c2r + alpha*res."""
+    B, C, Hin, Wfin, _ = z.shape
+    if out is None:
+        out = torch.empty((B, C, H, W), device=z.device, dtype=torch.float32)
+    check(lib().fdn_irfft_rows(_flat(z, "z"), ctypes.c_long(Wfin), ctypes.c_long(Hin * Wfin), _flat(out, "out"),
+                               ctypes.c_long(B * C), H, W, ctypes.c_float(scale), _flat(res, "res"),
+                               ctypes.c_float(alpha), stream()), "fdn_irfft_rows")
+    return out
+
+
+def fft_cols_fcaffn(z, amp, pha, wxa, wxp):
+    B, C, H, Wf, _ = z.shape
+    check(lib().fdn_fft_cols_fcaffn(_flat(z, "z"), _flat(amp, "amp"), _flat(pha, "pha"), _flat(wxa, "wxa"),
+                                    _flat(wxp, "wxp"), B, C, H, Wf, stream()), "fdn_fft_cols_fcaffn")
+    return z
+
+
+def fft_cols_fwd(z, want_abs, want_ang, rd_before=False, fix_real=True):
+    B, C, H, Wf, _ = z.shape
+    oa = torch.empty((B, C, H, Wf), device=z.device, dtype=torch.float32) if want_abs else None
+    og = torch.empty((B, C, H, Wf), device=z.device, dtype=torch.float32) if want_ang else None
+    check(lib().fdn_fft_cols_fwd(_flat(z, "z"), _flat(oa, "abs"), _flat(og, "ang"), ctypes.c_long(B * C), H, Wf,
+                                 int(rd_before), int(fix_real), stream()), "fdn_fft_cols_fwd")
+    return oa, og
+
+
+def fft_cols_inv_polar(mag, pha, H, Wf):
+    B, C, Hin, Wfin = mag.shape
+    z = torch.empty((B, C, H, Wf, 2), device=mag.device, dtype=torch.float32)
+    check(lib().fdn_fft_cols_inv_polar(_flat(mag, "mag"), _flat(pha, "pha"), Hin, Wfin, _flat(z, "z"),
+                                       ctypes.c_long(B * C), H, Wf, stream()), "fdn_fft_cols_inv_polar")
+    return z
+
+
+# ---------------------------------------------------------------------------------------------
+# dense convs, resampling, small helpers
+# ---------------------------------------------------------------------------------------------
+def conv2d(x, w, bias=None, stride=1, pad=0, act=ACT_NONE, res=None, res_before_act=False, post_add=0.0):
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    out = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32)
+    check(lib().fdn_conv2d(_flat(x, "x"), _flat(w, "w"), _flat(bias, "bias"), _flat(res, "res"), _flat(out, "out"),
+                           B, Cin, H, W, Cout, KH, KW, stride, pad, act, int(res_before_act), ctypes.c_float(post_add),
+                           stream()), "fdn_conv2d")
+    return out
+
+
+def conv_transpose4x4s2(x, w, bias, act):
+    B, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    out = torch.empty((B, Cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    check(lib().fdn_conv_transpose4x4s2(_flat(x, "x"), _flat(w, "w"), _flat(bias, "bias"), _flat(out, "out"),
+                                        B, Cin, H, W, Cout, act, stream()), "fdn_conv_transpose4x4s2")
+    return out
+
+
+def resample(x, mode, r=1):
+    B, C, H, W = x.shape
+    if mode in (RS_BILINEAR_HALF, RS_NEAREST_HALF):
+        shp = (B, C, H // 2, W // 2)
+    elif mode in (RS_BILINEAR_X2, RS_NEAREST_X2):
+        shp = (B, C, 2 * H, 2 * W)
+    else:
+        shp = (B, C * r * r, H // r, W // r)
+    out = torch.empty(shp, device=x.device, dtype=torch.float32)
+    check(lib().fdn_resample(_flat(x, "x"), _flat(out, "out"), ctypes.c_long(B * C), H, W, mode, r, stream()),
+          "fdn_resample")
+    return out
+
+
+def dw1x1_pad1(x, w, bias):
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, H + 2, W + 2), device=x.device, dtype=torch.float32)
+    check(lib().fdn_dw1x1_pad1(_flat(x, "x"), _flat(w, "w"), _flat(bias, "bias"), _flat(out, "out"), B, C, H, W,
+                               stream()), "fdn_dw1x1_pad1")
+    return out
+
+
+def avgpool3s2(x):
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    check(lib().fdn_avgpool3s2(_flat(x, "x"), _flat(out, "out"), ctypes.c_long(B * C), H, W, stream()), "fdn_avgpool3s2")
+    return out
+
+
+def global_avgpool(x):
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, 1, 1), device=x.device, dtype=torch.float32)
+    check(lib().fdn_global_avgpool(_flat(x, "x"), _flat(out, "out"), ctypes.c_long(B * C), ctypes.c_long(H * W),
+                                   stream()), "fdn_global_avgpool")
+    return out
+
+
+def se_apply(y, gate, shortcut):
+    B, C, H, W = y.shape
+    out = torch.empty_like(y)
+    check(lib().fdn_se_apply(_flat(y, "y"), _flat(gate, "gate"), _flat(shortcut, "shortcut"), _flat(out, "out"),
+                             ctypes.c_long(B * C), ctypes.c_long(H * W), stream()), "fdn_se_apply")
+    return out
+
+
+def scale_batch_(x, ratio):
+    B = x.shape[0]
+    check(lib().fdn_scale_batch(_flat(x, "x"), _flat(ratio, "ratio"), B, ctypes.c_long(x.numel() // B), stream()),
+          "fdn_scale_batch")
+    return x
+
+
+def gamma_curve(x, i_map, scale=40.0):
+    out = torch.empty_like(x)
+    check(lib().fdn_gamma_curve(_flat(x, "x"), _flat(i_map, "i_map"), _flat(out, "out"), ctypes.c_float(scale),
+                                ctypes.c_long(x.numel()), stream()), "fdn_gamma_curve")
+    return out

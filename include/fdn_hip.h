@@ -28,6 +28,7 @@ enum { FDN_OK = 0, FDN_ERR_ARG = 1, FDN_ERR_LAUNCH = 2, FDN_ERR_WORKSPACE = 3, F
 enum { FDN_ACT_NONE = 0, FDN_ACT_LEAKY = 1, FDN_ACT_RELU = 2, FDN_ACT_SIGMOID = 3, FDN_ACT_GELU = 4 };
 enum { FDN_PRO_NONE = 0, FDN_PRO_LN = 1, FDN_PRO_LN3_GATE = 2, FDN_PRO_LN_MULADD = 3 };
 enum { FDN_EPI_NONE = 0, FDN_EPI_RES = 1, FDN_EPI_MULADD = 2 };
+enum { FDN_RS_BILINEAR_HALF = 0, FDN_RS_BILINEAR_X2 = 1, FDN_RS_NEAREST_HALF = 2, FDN_RS_NEAREST_X2 = 3, FDN_RS_PIXEL_UNSHUFFLE = 4 };
 
 /* library version / build info: returns the ABI version (bumped on any signature change) */
 int fdn_abi_version(void);
@@ -104,6 +105,62 @@ int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, int C, int 
  * add = conv3_add(conv1_add(img)).  img [B][3][H][W]; w1_* [C][3]; w3_* [C][9]; outs [B][C][H][W]. */
 int fdn_img_mod_maps(const float* img, const float* w1_mul, const float* w3_mul, const float* w1_add,
                      const float* w3_add, float* mul, float* add, int B, int C, int H, int W, fdn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Full-image real 2-D FFT pipeline, norm='backward' (torch.fft.rfft2 / irfft2 at FDN_arch.py:90,98,
+ * :139,147, :411,418, :882-911).  Spectra are [planes][H][W/2+1] interleaved complex.
+ * Any even W and any H are accepted (mixed radix; large primes use an O(N*R) gather pass).
+ * fdn_fft_prepare(n): build the immutable twiddle table of length n now (else first use does). */
+int fdn_fft_prepare(int n);
+/* r2c along rows: in [rows][W] real -> out_c [rows][W/2+1] complex. */
+int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t stream);
+/* c2r along rows: spectrum rows of `in_row_bins` bins (>= W/2+1; leading-slice crop of
+ * irfft2(s=(H,W)), FDN_arch.py:147), planes `in_plane_bins` apart -> out [planes][H][W] real,
+ * out = scale * c2r(in) + alpha * res  (res may be NULL).  Im of bins 0 and W/2 is ignored. */
+int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane_bins, float* out, long planes, int H, int W,
+                   float scale, const float* res, float alpha, fdn_stream_t stream);
+/* FCAFFN spectral core, in place on z [B*C][H][Wf] (already row-transformed): column FFT ->
+ * replace_denormals -> * conv1_xa(amp) * exp(-i conv1_xp(pha)) -> column iFFT (FDN_arch.py:411-418,
+ * SURVEY App. C).  amp,pha [B][3][H][Wf]; wxa,wxp [C][3].  Unscaled (scale in fdn_irfft_rows). */
+int fdn_fft_cols_fcaffn(float* z, const float* amp, const float* pha, const float* wxa, const float* wxp, int B, int C,
+                        int H, int Wf, fdn_stream_t stream);
+/* Forward column FFT of z [planes][H][Wf] -> |z| and/or angle(z) as real planes (FDN_arch.py:91-92,
+ * :140-141, :883-884, :904).  rd_before: replace_denormals first; fix_real: force Im=+0 at the four
+ * self-conjugate bins of a real input (what a real-FFT library returns; keeps angle=+pi there). */
+int fdn_fft_cols_fwd(const float* z, float* out_abs, float* out_ang, long planes, int H, int Wf, int rd_before,
+                     int fix_real, fdn_stream_t stream);
+/* mag,pha real planes [planes][Hin][Wfin] -> z = mag*e^{i pha} on the leading (H,Wf) slice ->
+ * inverse column FFT -> z_out [planes][H][Wf] (FDN_arch.py:95-98, :144-147). */
+int fdn_fft_cols_inv_polar(const float* mag, const float* pha, int Hin, int Wfin, float* z_out, long planes, int H, int Wf,
+                           fdn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense convolutions, resampling and small MAR / LPNet helpers.
+ * fdn_conv2d: direct conv, groups=1, weight [Cout][Cin][KH][KW] (FDN_arch.py:57,:135,:174-175,
+ * :192-193,:196,:704,:720,:731,:804; LPNet_arch.py:49-62,:91).
+ *   v = conv + bias; if res && res_before_act: v += res; v = act(v); if res && !res_before_act:
+ *   v += res; out = v + post_add   (post_add = 1e-8 for the MAR heads, FDN_arch.py:241,248,255). */
+int fdn_conv2d(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int Cin, int H,
+               int W, int Cout, int KH, int KW, int stride, int pad, int act, int res_before_act, float post_add,
+               fdn_stream_t stream);
+/* ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1) + act; weight [Cin][Cout][4][4] (FDN_arch.py:194-195). */
+int fdn_conv_transpose4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
+                            int Cout, int act, fdn_stream_t stream);
+/* mode FDN_RS_*: bilinear 1/2, bilinear x2 (align_corners=False), nearest 1/2 ([::2,::2]), nearest x2,
+ * PixelUnshuffle(r) (FDN_arch.py:199-206,:230-233,:273-274,:719,:730,:875-876). `planes` = input planes. */
+int fdn_resample(const float* x, float* out, long planes, int H, int W, int mode, int r, fdn_stream_t stream);
+/* fourier_fuse.fpre[1] = Conv2d(n,n,1,padding=1,groups=n): out [B][C][H+2][W+2] (FDN_arch.py:126). */
+int fdn_dw1x1_pad1(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int W,
+                   fdn_stream_t stream);
+/* AvgPool2d(3,2,1) count_include_pad (LPNet_arch.py:94); AdaptiveAvgPool2d(1) (:71,:99); SE tail
+ * relu(y*gate+shortcut) (:75-80). */
+int fdn_avgpool3s2(const float* x, float* out, long planes, int H, int W, fdn_stream_t stream);
+int fdn_global_avgpool(const float* x, float* out, long planes, long P, fdn_stream_t stream);
+int fdn_se_apply(const float* y, const float* gate, const float* shortcut, float* out, long planes, long P,
+                 fdn_stream_t stream);
+/* x[b] *= ratio[b] (FDN_arch.py:213-219); out = 1-(1-x)^(scale*i_map) (FDN_arch.py:282-284). */
+int fdn_scale_batch(float* x, const float* ratio, int B, long per_batch, fdn_stream_t stream);
+int fdn_gamma_curve(const float* x, const float* i_map, float* out, float scale, long total, fdn_stream_t stream);
 
 #ifdef __cplusplus
 }
