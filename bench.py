@@ -109,12 +109,28 @@ class KernelTimer:
         return agg
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(cpu_count, affinity mask, cgroup cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(h=256, w=256):
     """Oracle (fp32, PyTorch CPU ops) on ONE h x w image; reported in 736x1280-equivalent images/s."""
     import fdn_oracle as O
     from weights import synth_state_dict
     from common import fdn_shapes, lpnet_weights
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     P = synth_state_dict(fdn_shapes(), 7, prefix_key="fdn/", tame=0.03)
     PL = lpnet_weights()
