@@ -1,0 +1,82 @@
+"""CPU: host-side logic of the drop-in modules and the C-ABI library (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import __graft_entry__ as entry  # noqa: F401  (puts the package on sys.path)
+from common import fdn_shapes, fdn_weights, lpnet_weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import fdn_hip
+    if not os.path.isfile(fdn_hip.lib_path()):
+        entry.build()
+    return fdn_hip.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "fdn_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(fdn_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"libfdn_hip.so does not export {n}"
+    assert lib.fdn_abi_version() >= 1
+    assert lib.fdn_error_string(1).decode().startswith("invalid argument")
+
+
+def test_argument_validation_without_gpu(lib):
+    # NULL pointers / bad sizes are rejected before any launch
+    assert lib.fdn_fdsa_core(None, None, None, None, 1, 38, 32, 32, None) == 1
+    assert lib.fdn_rfft_rows(None, None, ctypes.c_long(4), 16, None) == 1
+
+
+def test_state_dict_layout_matches_reference():
+    from basicsr.models.archs.FDN_arch import FDN
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    net = FDN()
+    sd = net.state_dict()
+    ref = fdn_shapes()                      # key -> shape table captured from the reference FDN()
+    assert len(sd) == 1503 and set(sd) == set(ref)
+    assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    net.load_state_dict(fdn_weights(), strict=True)
+    assert sum(p.numel() for p in net.parameters()) == 8030489
+    assert not any(p.requires_grad for p in net.net_a.parameters())      # FDN_arch.py:858-859
+    lp = I_predict_net()
+    lp.load_state_dict(lpnet_weights(), strict=True)
+    assert len(lp.state_dict()) == 292
+
+
+def test_star_import_surface():
+    ns = {}
+    exec("from basicsr.models.archs.FDN_arch import *\nfrom basicsr.models.archs.LPNet_arch import *", ns)
+    for name in ("FDN", "F", "torch", "nn", "np", "rearrange", "I_predict_net", "transforms"):
+        assert name in ns, name
+    from basicsr.models.archs import define_network
+    assert type(define_network({"type": "FDN"})).__name__ == "FDN"
+
+
+def test_no_cpu_fallback():
+    from basicsr.models.archs.FDN_arch import FDN
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    import fdn_hip
+    with pytest.raises(fdn_hip.FdnHipError):
+        FDN().eval()(torch.rand(1, 3, 32, 32), ratio_i=torch.rand(1, 1))
+    with pytest.raises(fdn_hip.FdnHipError):
+        I_predict_net().eval()(torch.rand(1, 3, 32, 32))
+    with pytest.raises(ValueError):
+        FDN().eval()(torch.rand(1, 3, 32, 32))
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, "fdn-tip2025_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".sh")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "fdn_oracle" not in txt and "oracle/" not in txt, os.path.join(dp, f)
