@@ -6,214 +6,306 @@
 // project_out), :456/:474 (FDFFN project_in/out), :421/:428 (FCAFFN), :685-686 (Fuse) and the
 // 62 1x1 convs of MAR (:78-86, :125-134, :168-190), with the surrounding channel-LayerNorm
 // (:313-342), the v_value gating (:633-638), `norm(x)*x1+x1` (:420), the residual adds (:671-675)
-// and `x*mul+add` (:423) folded into the operand staging / epilogue.
+// and `x*mul+add` (:423) folded into the operand path / epilogue.
 //
-// Mapping (CDNA4): pixels are the contiguous axis of NCHW, so the GEMM is
-//   D[n][p] = A[n][k] * B[k][p],  A = weights, B = activations,
-// on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-exact fmaf chain).  One 256-thread
-// workgroup owns 128 consecutive pixels of one image; wave w owns pixels [32w, 32w+32) and MT
-// 32-row tiles of output channels, so the accumulator of reg r / lane l is
-//   n = 32*mt + (r&3) + 8*(r>>2) + 4*(l>>5),  p = 32*w + (l&31)
-// and every store instruction writes two full 128-byte lines.  K is streamed through LDS in
-// chunks of 32 channels (global -> registers while the previous chunk's MFMAs run, registers ->
-// LDS after the barrier).  When N needs more than one pass of MT tiles the workgroup loops over
-// the passes itself so the activation tile is re-read by the same CU (L1/L2 hit), never by a
-// workgroup on another XCD.
+// Mapping (CDNA4, v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-exact fmaf chain):
+//   D[n][p] = A[n][k] * B[k][p],  A = weights, B = activations.
+// Pixels are the contiguous axis of NCHW and sit on the MFMA column (lane) axis, so
+//   * the B operand of lane l for k-step s is x[k = 2s + (l>>5)][p = p0 + (l&31)]: one coalesced
+//     global dword load (two 128-B lines per wave-instruction) straight into the VGPR the MFMA
+//     reads - activations never touch LDS and each wave owns its 32-pixel strip exclusively;
+//   * the accumulator of reg r is row n = 32*mt + (r&3) + 8*(r>>2) + 4*(l>>5), column p, so every
+//     store instruction writes two full 128-byte lines;
+//   * only the weights (shared by all waves) live in LDS, transposed to [k][n]; when the K x (MT*32)
+//     slice fits they are loaded once per workgroup ("resident") and the persistent tile loop runs
+//     without any barrier, otherwise 32-deep K chunks are double-buffered with one barrier a step.
+// The next step's activations are prefetched into a second register set while the current step's
+// MFMAs issue.  Prologues (LayerNorm, 3xLayerNorm * v_value, LayerNorm * x1 + x1) are applied in
+// registers between the load and the MFMA.
 #include "common.hpp"
 
 namespace {
 
-constexpr int BP = 128;   // pixels per workgroup
-constexpr int KC = 32;    // K chunk staged in LDS
-constexpr int WPAD = 1;   // Ws row padding (transposing store: bank = k + n)
-
+constexpr int KC = 32;     // K chunk (16 MFMA k-steps)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct Pro {
-    // per-thread constants of the prologue for its 4 pixels
-    float mu[3][4], rs[3][4];
+struct Geo {
+    int tiles_per_img;     // pixel tiles (NW*32 px) per image
+    int total_tiles;       // B * tiles_per_img
+    int resident;          // whole K x (MT*32) weight slice kept in LDS
 };
 
-template <int MT>
-__global__ __launch_bounds__(256) void conv1x1_kernel(fdn_conv1x1_desc d) {
-    __shared__ float Xs[KC][BP];
-    __shared__ float Ws[KC][MT * 32 + WPAD];
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t mk_rsrc(const float* base, unsigned bytes) {
+    // raw buffer, stride 0: offsets >= bytes read 0 / drop the store (K, N and plane tails for free)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+template <int MT, int PRO, int NW>
+__global__ __launch_bounds__(NW * 64) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = NW * 64;
+    constexpr int WS = MT * 32 + 1;            // LDS row stride of the transposed weight chunk
+    constexpr int CH = KC * WS;                // floats per chunk buffer
+    const int K = d.K, N = d.N;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int nch = (K + KC - 1) / KC;
+    const int Kp = nch * KC;
+    float* tg = smem;                          // gamma[Kp]
+    float* tb = smem + Kp;                     // beta[Kp]
+    float* Wl = smem + 2 * Kp;                 // weight chunks
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int b = blockIdx.y;
-    const long p0 = (long)blockIdx.x * BP;
-    const int P = d.P, K = d.K, N = d.N;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5, ln = lane & 31;
 
-    // ---- staging geometry for X: thread owns pixel quad pq (4 px) and rows kr + 8*i -----------
-    const int pq = (tid & 31) * 4;
-    const int kr = tid >> 5;                  // 0..7
-    const long pg = p0 + pq;                  // first global pixel of the quad
-    const bool vec = d.vec4 && (pg + 3 < P);
-    const int nvalid = pg >= P ? 0 : (pg + 4 <= P ? 4 : (int)(P - pg));
-
-    const int pro = d.pro;
-    const int E = d.ln_group;                 // channels per LN group (LN3_GATE: E; else K)
-    Pro st;
-    if (pro != FDN_PRO_NONE) {
-        const int G = (pro == FDN_PRO_LN3_GATE) ? 3 : 1;
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = (g < G) && (j < nvalid);
-                const float* sp = d.stats + ((long)b * G + (g < G ? g : 0)) * 2 * P;
-                st.mu[g][j] = ok ? sp[pg + j] : 0.f;
-                st.rs[g][j] = ok ? sp[P + pg + j] : 0.f;
-            }
+    for (int i = tid; i < Kp; i += NT) {
+        tg[i] = (PRO != FDN_PRO_NONE && i < K) ? d.gamma[i] : 0.f;
+        tb[i] = (PRO != FDN_PRO_NONE && i < K) ? d.beta[i] : 0.f;
     }
 
-    auto load_x = [&](int k, float (&v)[4]) {
-        // raw fetch of channel k (concat of up to 3 segments) for this thread's pixel quad
-        const float* src;
-        if (k < d.kseg[0]) src = d.x[0] + (long)b * d.xbs[0] + (long)k * P;
-        else if (k < d.kseg[0] + d.kseg[1]) src = d.x[1] + (long)b * d.xbs[1] + (long)(k - d.kseg[0]) * P;
-        else src = d.x[2] + (long)b * d.xbs[2] + (long)(k - d.kseg[0] - d.kseg[1]) * P;
-        if (vec) {
-            const float4 t = *reinterpret_cast<const float4*>(src + pg);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = j < nvalid ? src[pg + j] : 0.f;
-        }
-    };
-    auto load_aux = [&](int k, float (&v)[4]) {  // second operand (v_value / x1), channel k of d.xb
-        const float* src = d.xb + (long)b * d.xbbs + (long)k * P;
-        if (vec) {
-            const float4 t = *reinterpret_cast<const float4*>(src + pg);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = j < nvalid ? src[pg + j] : 0.f;
-        }
-    };
-
-    const int nchunks = (K + KC - 1) / KC;
+    const int E = d.ln_group;
+    const int ks0 = d.kseg[0], ks01 = d.kseg[0] + d.kseg[1];
     const int npass = (N + MT * 32 - 1) / (MT * 32);
+    constexpr int WPT = (KC * MT * 32) / NT;   // weight elements per thread per chunk
 
     for (int pass = 0; pass < npass; ++pass) {
         const int nbase = pass * MT * 32;
+
+        // ---- weight chunk loader: W[n][k] (lanes along k) -> regs -> Wl[buf][k][n] ---------------
+        float wr[WPT];
+        auto w_fetch = [&](int c) {
+            const int kk = tid & 31, k = c * KC + kk;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int n = nbase + (tid >> 5) + (NT / 32) * i;
+                wr[i] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
+            }
+        };
+        auto w_stash = [&](int buf) {
+            const int kk = tid & 31;
+            float* dst = Wl + buf * CH + kk * WS;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) dst[(tid >> 5) + (NT / 32) * i] = wr[i];
+        };
+        __syncthreads();                       // previous pass finished reading Wl; tables written
+        if (g.resident) {
+            for (int c = 0; c < nch; ++c) { w_fetch(c); w_stash(c); }
+        } else {
+            w_fetch(0);
+            w_stash(0);
+        }
+        __syncthreads();
+
+        // ---- persistent loop over (tile, chunk) steps ---------------------------------------------
+        int tile = blockIdx.x, c = 0;
+        bool live = tile < g.total_tiles;
+
+        float xa[16], xb[16];                  // current / prefetched activations
+        float ya[16], yb[16];                  // second operand (v_value / x1) for PRO 2,3
+        float mu[3], rs[3];                    // LayerNorm statistics of this lane's pixel
+
+        struct Tile { int b; unsigned pix; bool ok; };
+        auto tile_setup = [&](int t) {
+            Tile r;
+            r.b = t / g.tiles_per_img;
+            const unsigned p_ = (unsigned)(t - r.b * g.tiles_per_img) * (NW * 32) + wave * 32 + ln;
+            r.ok = p_ < P;
+            r.pix = r.ok ? p_ : P - 1;         // clamp: harmless loads, never stored
+            return r;
+        };
+        auto x_issue = [&](const Tile& t, int c_, float (&xv)[16], float (&yv)[16]) {
+            const rsrc_t r0 = mk_rsrc(d.x[0] + (long)t.b * d.xbs[0], (unsigned)ks0 * P4);
+            const rsrc_t r1 = mk_rsrc(d.x[1] + (long)t.b * d.xbs[1], (unsigned)d.kseg[1] * P4);
+            const rsrc_t r2 = mk_rsrc(d.x[2] + (long)t.b * d.xbs[2], (unsigned)d.kseg[2] * P4);
+            const unsigned voff = (kh * P + t.pix) * 4u;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = c_ * KC + 2 * s;                      // wave-uniform, even
+                if (k < ks0) xv[s] = bload(r0, voff, (unsigned)k * P4);
+                else if (k < ks01) xv[s] = bload(r1, voff, (unsigned)(k - ks0) * P4);
+                else xv[s] = bload(r2, voff, (unsigned)(k - ks01) * P4);
+            }
+            if (PRO == FDN_PRO_LN3_GATE) {
+                const rsrc_t ry = mk_rsrc(d.xb + (long)t.b * d.xbbs, (unsigned)E * P4);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int k = c_ * KC + 2 * s + kh;
+                    const int e = k - ((k >= E) + (k >= 2 * E)) * E;
+                    yv[s] = bload(ry, ((unsigned)e * P + t.pix) * 4u, 0u);
+                }
+            } else if (PRO == FDN_PRO_LN_MULADD) {
+                const rsrc_t ry = mk_rsrc(d.xb + (long)t.b * d.xbbs, (unsigned)K * P4);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) yv[s] = bload(ry, voff, (unsigned)(c_ * KC + 2 * s) * P4);
+            }
+        };
+        auto stats_load = [&](const Tile& t) {
+            if (PRO == FDN_PRO_NONE) return;
+            constexpr int G = (PRO == FDN_PRO_LN3_GATE) ? 3 : 1;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q < G) {
+                    const float* sp = d.stats + ((long)t.b * G + q) * 2 * P;
+                    mu[q] = sp[t.pix];
+                    rs[q] = sp[P + t.pix];
+                } else { mu[q] = 0.f; rs[q] = 0.f; }
+            }
+        };
+
         f32x16 acc[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-        float xr[4][4];          // staged X: rows kr + 8*i
-        float wr[MT * 4];        // staged W: element e = tid + 256*i of the [MT*32][32] chunk
-
-        auto fetch = [&](int kc) {
-            const int k0 = kc * KC;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = k0 + kr + 8 * i;
-                if (k < K) {
-                    load_x(k, xr[i]);
-                    if (pro == FDN_PRO_LN) {
-                        const float ga = d.gamma[k], be = d.beta[k];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) xr[i][j] = (xr[i][j] - st.mu[0][j]) * st.rs[0][j] * ga + be;
-                    } else if (pro == FDN_PRO_LN3_GATE) {
-                        const int g = k / E, e = k - g * E;
-                        const float ga = d.gamma[k], be = d.beta[k];
-                        float vv[4];
-                        load_aux(e, vv);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float mu = g == 0 ? st.mu[0][j] : (g == 1 ? st.mu[1][j] : st.mu[2][j]);
-                            const float rs = g == 0 ? st.rs[0][j] : (g == 1 ? st.rs[1][j] : st.rs[2][j]);
-                            xr[i][j] = ((xr[i][j] - mu) * rs * ga + be) * vv[j];
-                        }
-                    } else if (pro == FDN_PRO_LN_MULADD) {
-                        const float ga = d.gamma[k], be = d.beta[k];
-                        float x1[4];
-                        load_aux(k, x1);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            xr[i][j] = ((xr[i][j] - st.mu[0][j]) * st.rs[0][j] * ga + be) * x1[j] + x1[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j >= nvalid) xr[i][j] = 0.f;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xr[i][j] = 0.f;
-                }
-            }
-            // weights: W[n][k], lanes run along k (coalesced 128-byte rows)
-            const int kk = tid & 31;
-#pragma unroll
-            for (int i = 0; i < MT * 4; ++i) {
-                const int nl = (tid >> 5) + 8 * i;
-                const int n = nbase + nl, k = k0 + kk;
-                wr[i] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
-            }
-        };
-        auto stash = [&]() {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<float4*>(&Xs[kr + 8 * i][pq]) = make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
-            const int kk = tid & 31;
-#pragma unroll
-            for (int i = 0; i < MT * 4; ++i) Ws[kk][(tid >> 5) + 8 * i] = wr[i];
-        };
-
-        fetch(0);
-        for (int kc = 0; kc < nchunks; ++kc) {
-            __syncthreads();            // previous chunk's reads are done
-            stash();
-            __syncthreads();
-            if (kc + 1 < nchunks) fetch(kc + 1);
-            const int kh = lane >> 5, ln = lane & 31;
-#pragma unroll
-            for (int kk = 0; kk < KC; kk += 2) {
-                const float bv = Xs[kk + kh][wave * 32 + ln];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float av = Ws[kk + kh][m * 32 + ln];
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
-                }
-            }
+        Tile cur = tile_setup(live ? tile : 0);
+        if (live) {
+            stats_load(cur);
+            x_issue(cur, 0, xa, ya);
         }
+        int step = 0;
+        while (live) {
+            // next step
+            int ntile = tile, nc = c + 1;
+            if (nc == nch) { nc = 0; ntile = tile + gridDim.x; }
+            const bool nlive = ntile < g.total_tiles;
+            Tile nxt = cur;
+            if (nlive) {
+                if (nc == 0) nxt = tile_setup(ntile);
+                x_issue(nxt, nc, xb, yb);                          // prefetch: overlaps the MFMAs below
+                if (!g.resident) w_fetch(nc);
+            }
 
-        // ---- epilogue ----------------------------------------------------------------------
-        const long p = p0 + wave * 32 + (lane & 31);
-        if (p < P) {
+            // ---- compute step (tile, c) -----------------------------------------------------------
+            const float* Wc = Wl + (g.resident ? c : (step & 1)) * CH;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = nbase + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (n < N) {
-                        float v = acc[m][r];
-                        if (d.bias) v += d.bias[n];
-                        v = apply_act(v, d.act);
-                        const long o = (long)n * P + p;
-                        if (d.epi == FDN_EPI_RES) v += d.res[(long)b * d.rbs + o];
-                        else if (d.epi == FDN_EPI_MULADD) v = v * d.mul[(long)b * d.mbs + o] + d.add[(long)b * d.mbs + o];
-                        d.out[(long)b * d.obs + o] = v;
+            for (int s = 0; s < 16; ++s) {
+                float bv = xa[s];
+                if (PRO != FDN_PRO_NONE) {
+                    const int k = c * KC + 2 * s + kh;
+                    const float ga = tg[k], be = tb[k];
+                    if (PRO == FDN_PRO_LN) {
+                        bv = (bv - mu[0]) * rs[0] * ga + be;
+                    } else if (PRO == FDN_PRO_LN3_GATE) {
+                        const int q = (k >= E) + (k >= 2 * E);
+                        const float m_ = q == 0 ? mu[0] : (q == 1 ? mu[1] : mu[2]);
+                        const float r_ = q == 0 ? rs[0] : (q == 1 ? rs[1] : rs[2]);
+                        bv = ((bv - m_) * r_ * ga + be) * ya[s];
+                    } else {
+                        bv = ((bv - mu[0]) * rs[0] * ga + be) * ya[s] + ya[s];
                     }
                 }
+                const float* wrow = Wc + (2 * s + kh) * WS + ln;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[m * 32], bv, acc[m], 0, 0, 0);
+            }
+
+            // ---- epilogue at the last chunk of a tile --------------------------------------------------
+            if (c == nch - 1) {
+                if (cur.ok) {
+                    const unsigned nb4 = (unsigned)N * P4;
+                    const rsrc_t ro = mk_rsrc(d.out + (long)cur.b * d.obs, nb4);
+                    const rsrc_t rr = mk_rsrc(d.res ? d.res + (long)cur.b * d.rbs : d.out, d.res ? nb4 : 0u);
+                    const rsrc_t rm = mk_rsrc(d.mul ? d.mul + (long)cur.b * d.mbs : d.out, d.mul ? nb4 : 0u);
+                    const rsrc_t rd = mk_rsrc(d.add ? d.add + (long)cur.b * d.mbs : d.out, d.add ? nb4 : 0u);
+                    const unsigned voff = (4u * kh * P + cur.pix) * 4u;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int nrow = nbase + m * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh per lane
+                            const unsigned soff = (unsigned)nrow * P4;
+                            float v = acc[m][r];
+                            if (d.bias) { const int n = nrow + 4 * kh; v += (n < N) ? d.bias[n] : 0.f; }
+                            v = apply_act(v, d.act);
+                            if (d.epi == FDN_EPI_RES) v += bload(rr, voff, soff);
+                            else if (d.epi == FDN_EPI_MULADD) v = v * bload(rm, voff, soff) + bload(rd, voff, soff);
+                            bstore(v, ro, voff, soff);          // rows >= N fall outside the descriptor
+                        }
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            }
+
+            if (!g.resident) {
+                if (nlive) w_stash((step + 1) & 1);
+                __syncthreads();
+            }
+            // advance
+            if (nlive && nc == 0) { cur = nxt; stats_load(cur); }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { xa[s] = xb[s]; ya[s] = yb[s]; }
+            tile = ntile; c = nc; live = nlive;
+            ++step;
         }
     }
 }
 
 int pick_mt(int N) {
-    // fewest wasted 32-row tiles, then fewest passes; MT <= 5 keeps the accumulator at 80 VGPRs
+    // fewest computed 32-row tiles, then fewest passes; MT <= 5 keeps the accumulator at 80 VGPRs
     const int tiles = (N + 31) / 32;
     int best = 1, best_cost = 1 << 30;
     for (int mt = 1; mt <= 5; ++mt) {
         const int passes = (tiles + mt - 1) / mt;
-        const int cost = passes * mt * 100 + passes;   // computed tiles dominate, then passes
+        const int cost = passes * mt * 100 + passes;
         if (cost < best_cost || (cost == best_cost && mt > best)) { best_cost = cost; best = mt; }
     }
     return best;
+}
+
+int g_num_cu = 0;
+
+template <int MT, int PRO, int NW>
+int launch(const fdn_conv1x1_desc& d, hipStream_t s) {
+    const int nch = (d.K + KC - 1) / KC;
+    const size_t tab = 2UL * nch * KC * sizeof(float);
+    const size_t chunk = (size_t)KC * (MT * 32 + 1) * sizeof(float);
+    Geo g;
+    g.resident = (tab + nch * chunk <= 96 * 1024) ? 1 : 0;
+    const size_t lds = tab + (g.resident ? nch : 2) * chunk;
+    g.tiles_per_img = cdiv(d.P, NW * 32);
+    g.total_tiles = d.B * g.tiles_per_img;
+    auto kern = conv1x1_kernel<MT, PRO, NW>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return FDN_ERR_LAUNCH;
+    }
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    // persistent grid: as many workgroups as can be co-resident (LDS / register limited), capped by the work
+    int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    if (per_cu > 2) per_cu = 2;                                 // 8-wave workgroups: 2 per CU = 4 waves per SIMD
+    if (per_cu < 1) per_cu = 1;
+    int grid = g_num_cu * per_cu;
+    if (grid > g.total_tiles) grid = g.total_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, d, g);
+    return fdn_launch_status();
+}
+
+template <int MT>
+int launch_pro(const fdn_conv1x1_desc& d, hipStream_t s) {
+    switch (d.pro) {
+        case FDN_PRO_NONE: return launch<MT, FDN_PRO_NONE, 8>(d, s);
+        case FDN_PRO_LN: return launch<MT, FDN_PRO_LN, 8>(d, s);
+        case FDN_PRO_LN3_GATE: return launch<MT, FDN_PRO_LN3_GATE, 8>(d, s);
+        case FDN_PRO_LN_MULADD: return launch<MT, FDN_PRO_LN_MULADD, 8>(d, s);
+        default: return FDN_ERR_ARG;
+    }
 }
 
 }  // namespace
@@ -231,22 +323,19 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
     if (d.pro == FDN_PRO_LN_MULADD) FDN_CHECK_ARG(d.xb);
     if (d.epi == FDN_EPI_RES) FDN_CHECK_ARG(d.res);
     if (d.epi == FDN_EPI_MULADD) FDN_CHECK_ARG(d.mul && d.add);
-    // float4 path: every plane base 16-byte aligned and P a multiple of 4
-    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    bool vec = (d.P % 4 == 0) && al(d.x[0]) && (d.xbs[0] % 4 == 0);
-    if (d.kseg[1]) vec = vec && al(d.x[1]) && (d.xbs[1] % 4 == 0);
-    if (d.kseg[2]) vec = vec && al(d.x[2]) && (d.xbs[2] % 4 == 0);
-    if (d.xb) vec = vec && al(d.xb) && (d.xbbs % 4 == 0);
-    d.vec4 = vec ? 1 : 0;
-
-    dim3 grid(cdiv(d.P, BP), d.B), block(256);
+    d.vec4 = 0;
+    // 32-bit buffer offsets: every per-image plane set must stay below 4 GiB (incl. the padded K / N tails)
+    {
+        const unsigned long long lim = 0xFFFFFFFFull, P4 = 4ull * d.P;
+        if ((unsigned long long)(d.K + 40) * P4 > lim || (unsigned long long)(d.N + 200) * P4 > lim) return FDN_ERR_UNSUPPORTED;
+        if (d.kseg[1] > 0 && ((d.kseg[0] & 1) || (d.kseg[1] & 1))) return FDN_ERR_UNSUPPORTED;   // k-step pairs must not straddle segments
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (pick_mt(d.N)) {
-        case 1: hipLaunchKernelGGL(conv1x1_kernel<1>, grid, block, 0, s, d); break;
-        case 2: hipLaunchKernelGGL(conv1x1_kernel<2>, grid, block, 0, s, d); break;
-        case 3: hipLaunchKernelGGL(conv1x1_kernel<3>, grid, block, 0, s, d); break;
-        case 4: hipLaunchKernelGGL(conv1x1_kernel<4>, grid, block, 0, s, d); break;
-        default: hipLaunchKernelGGL(conv1x1_kernel<5>, grid, block, 0, s, d); break;
+        case 1: return launch_pro<1>(d, s);
+        case 2: return launch_pro<2>(d, s);
+        case 3: return launch_pro<3>(d, s);
+        case 4: return launch_pro<4>(d, s);
+        default: return launch_pro<5>(d, s);
     }
-    return fdn_launch_status();
 }
