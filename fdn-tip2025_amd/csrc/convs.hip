@@ -11,6 +11,10 @@
 // weight address is wave-uniform so it rides the scalar cache.
 #include "common.hpp"
 
+// MFMA implicit-GEMM path for 3x3 / stride 1 / pad 1 (conv3x3.hip); FDN_ERR_UNSUPPORTED = not covered
+int fdn_conv3x3_mfma(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int Cin, int H,
+                     int W, int Cout, int act, int res_before_act, float post_add, hipStream_t s);
+
 namespace {
 
 constexpr int OCB = 8;
@@ -213,6 +217,11 @@ extern "C" int fdn_conv2d(const float* x, const float* w, const float* bias, con
                           int H, int W, int Cout, int KH, int KW, int stride, int pad, int act, int res_before_act,
                           float post_add, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
+        const int rc = fdn_conv3x3_mfma(x, w, bias, res, out, B, Cin, H, W, Cout, act, res_before_act, post_add,
+                                        static_cast<hipStream_t>(stream));
+        if (rc != FDN_ERR_UNSUPPORTED) return rc;
+    }
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out;
     a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;

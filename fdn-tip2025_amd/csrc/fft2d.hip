@@ -73,11 +73,14 @@ bool make_plan(int N, int tabN, Plan* p) {
     p->nst = 0;
     int n = N;
     auto push = [&](int r) { if (p->nst < MAX_STAGES) p->radix[p->nst++] = r; };
+    int n2 = n, odd[MAX_STAGES], nodd = 0;
+    while (n2 % 2 == 0) n2 /= 2;
+    for (int f = 3; (long)f * f <= n2; f += 2)
+        while (n2 % f == 0) { if (nodd < MAX_STAGES) odd[nodd++] = f; n2 /= f; }
+    if (n2 > 1 && nodd < MAX_STAGES) odd[nodd++] = n2;
+    for (int i = nodd - 1; i >= 0; --i) { push(odd[i]); n /= odd[i]; }     // largest odd prime first
     while (n % 4 == 0) { push(4); n /= 4; }
     while (n % 2 == 0) { push(2); n /= 2; }
-    for (int f = 3; (long)f * f <= n; f += 2)
-        while (n % f == 0) { push(f); n /= f; }
-    if (n > 1) push(n);
     int prod = 1;
     for (int i = 0; i < p->nst; ++i) prod *= p->radix[i];
     if (prod != N || tabN % N != 0) return false;
@@ -96,13 +99,63 @@ __device__ __forceinline__ float2 twd(const float2* __restrict__ tw, int idx) {
     return INV ? make_float2(w.x, -w.y) : w;
 }
 
-template <bool INV>
+// odd-prime pass with the whole radix-R butterfly in registers (naive DFT_R, R^2 complex MACs);
+// the R roots of unity sit in registers too, so the inner loop has no memory traffic at all
+template <bool INV, int R>
+__device__ void fft_pass_reg(const float2* src, float2* dst, int N, int Ns, int nseq, int ss, int es, bool seq_fast,
+                             const float2* __restrict__ tw, int tab_mul) {
+    const int T = N / R;
+    const int L = Ns * R;
+    const int tws = tab_mul * (N / L);
+    const int twr = tab_mul * (N / R);
+    float2 wR[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) wR[t] = twd<INV>(tw, t * twr);
+    const int jobs = T * nseq;
+    for (int job = threadIdx.x; job < jobs; job += NT) {
+        int i, s;
+        if (seq_fast) { i = job / nseq; s = job - i * nseq; }
+        else { s = job / T; i = job - s * T; }
+        const int k = i % Ns;
+        const int j = (i - k) * R + k;
+        const float2* sp = src + s * ss;
+        float2* dp = dst + s * ss;
+        float2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = sp[(i + r * T) * es];
+        if (k) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twd<INV>(tw, r * k * tws));
+        }
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            float2 acc = u[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                const float2 w = wR[(r * o) % R];
+                acc.x = fmaf(u[r].x, w.x, fmaf(-u[r].y, w.y, acc.x));
+                acc.y = fmaf(u[r].x, w.y, fmaf(u[r].y, w.x, acc.y));
+            }
+            dp[(j + o * Ns) * es] = acc;
+        }
+    }
+}
+
+template <bool INV, bool BIG>
 __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, int nseq, int ss, int es, bool seq_fast,
                          const float2* __restrict__ tw, int tab_mul) {
     const int T = N / R;
     const int L = Ns * R;
     const int tws = tab_mul * (N / L);        // W_L^e = tw[e * tws]
     const int jobs = T * nseq;
+    switch (R) {
+        case 3: fft_pass_reg<INV, 3>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
+        case 5: fft_pass_reg<INV, 5>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
+        case 7: fft_pass_reg<INV, 7>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
+        case 17: if (BIG) { fft_pass_reg<INV, 17>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
+        case 23: if (BIG) { fft_pass_reg<INV, 23>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
+        default: break;
+    }
     if (R != 2 && R != 4) {
         // gather form, one output element per job: out[m] = sum_r in[i + r*T] * W_L^{r*m}
         const int jobs2 = jobs * R;
@@ -164,14 +217,14 @@ __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, i
 }
 
 // run all passes; returns the buffer holding the result
-template <bool INV>
-__device__ float2* fft_run(float2* a, float2* b, const Plan& p, int nseq, int ss, int es, bool seq_fast) {
+template <bool INV, bool BIG>
+__device__ float2* fft_run(float2* a, float2* b, const Plan& p, const float2* tw, int nseq, int ss, int es, bool seq_fast) {
     int Ns = 1;
     float2* src = a;
     float2* dst = b;
     for (int st = 0; st < p.nst; ++st) {
         __syncthreads();
-        fft_pass<INV>(src, dst, p.N, Ns, p.radix[st], nseq, ss, es, seq_fast, p.tw, p.tab_mul);
+        fft_pass<INV, BIG>(src, dst, p.N, Ns, p.radix[st], nseq, ss, es, seq_fast, tw, p.tab_mul);
         Ns *= p.radix[st];
         float2* t = src; src = dst; dst = t;
     }
@@ -182,19 +235,22 @@ __device__ float2* fft_run(float2* a, float2* b, const Plan& p, int nseq, int ss
 // ------------------------------------------------------------------------------------------
 // rows: r2c
 // ------------------------------------------------------------------------------------------
+template <bool BIG>
 __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__ in, float2* __restrict__ out, int W, long R,
-                                                       int rpb, Plan p) {
+                                                       int rpb, const Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = W / 2, Wf = M + 1;
     float2* A = reinterpret_cast<float2*>(smem);
     float2* Bf = A + (long)rpb * M;
+    float2* twl = Bf + (long)rpb * M;
+    for (int i = threadIdx.x; i < W; i += NT) twl[i] = p.tw[i];
     const long row0 = (long)blockIdx.x * rpb;
     const int nrow = (int)min((long)rpb, R - row0);
     for (int idx = threadIdx.x; idx < rpb * M; idx += NT) {
         const int s = idx / M, m = idx - s * M;
         A[idx] = (s < nrow) ? reinterpret_cast<const float2*>(in + (row0 + s) * W)[m] : make_float2(0.f, 0.f);
     }
-    float2* Z = fft_run<false>(A, Bf, p, rpb, M, 1, false);
+    float2* Z = fft_run<false, BIG>(A, Bf, p, twl, rpb, M, 1, false);
     // split: X[k] = E[k] + W_N^k O[k],  E = (Z[k]+conj Z[M-k])/2,  O = -i (Z[k]-conj Z[M-k])/2
     const int tw1 = p.tab_mul / 2;              // table is W_W^t:  tab_mul = W / M = 2  -> stride 1
     for (int idx = threadIdx.x; idx < nrow * Wf; idx += NT) {
@@ -208,7 +264,7 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
         if (k == 0) x = make_float2(e.x + o.x, 0.0f);
         else if (k == M) x = make_float2(e.x - o.x, 0.0f);
         else {
-            const float2 w = p.tw[k * tw1];
+            const float2 w = twl[k * tw1];
             x = make_float2(e.x + (o.x * w.x - o.y * w.y), e.y + (o.x * w.y + o.y * w.x));
         }
         out[(row0 + s) * Wf + k] = x;
@@ -216,14 +272,18 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
 }
 
 // rows: c2r.  in rows have stride in_ws bins (>= M+1: leading-slice crop of a wider spectrum)
+template <bool BIG>
 __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict__ in, long in_ws, long in_plane_rows,
                                                         long in_plane_stride, float* __restrict__ out, int W, int H, long R,
                                                         int rpb, float scale, const float* __restrict__ res, float alpha,
-                                                        Plan p) {
+                                                        const Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = W / 2;
     float2* A = reinterpret_cast<float2*>(smem);
     float2* Bf = A + (long)rpb * M;
+    float2* twl = Bf + (long)rpb * M;
+    for (int i = threadIdx.x; i < W; i += NT) twl[i] = p.tw[i];
+    __syncthreads();
     const long row0 = (long)blockIdx.x * rpb;
     const int nrow = (int)min((long)rpb, R - row0);
     const int tw1 = p.tab_mul / 2;
@@ -239,13 +299,13 @@ __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict
             // E = (X[k] + conj X[M-k])/2 ; O = (X[k] - conj X[M-k])/2 * W_N^{-k} ; Z = E + i O
             const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));
             const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y + xc.y));
-            const float2 w = p.tw[k * tw1];                     // conj -> W^{-k}
+            const float2 w = twl[k * tw1];                      // conj -> W^{-k}
             const float2 o = make_float2(d.x * w.x + d.y * w.y, d.y * w.x - d.x * w.y);
             z = make_float2(e.x - o.y, e.y + o.x);
         }
         A[idx] = z;
     }
-    float2* Z = fft_run<true>(A, Bf, p, rpb, M, 1, false);
+    float2* Z = fft_run<true, BIG>(A, Bf, p, twl, rpb, M, 1, false);
     for (int idx = threadIdx.x; idx < nrow * M; idx += NT) {
         const int s = idx / M, m = idx - s * M;
         const long row = row0 + s;
@@ -287,12 +347,14 @@ struct ColArgs {
 
 enum { COL_FCAFFN = 0, COL_FWD = 1, COL_INV_POLAR = 2 };
 
-template <int MODE>
-__global__ __launch_bounds__(NT) void fft_cols_kernel(ColArgs a, Plan p) {
+template <int MODE, bool BIG>
+__global__ __launch_bounds__(NT) void fft_cols_kernel(ColArgs a, const Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = a.H, Wf = a.Wf, tc = a.tc;
     float2* A = reinterpret_cast<float2*>(smem);
     float2* Bf = A + (long)H * tc;
+    float2* twl = Bf + (long)H * tc;
+    for (int i = threadIdx.x; i < H; i += NT) twl[i] = p.tw[i];
     const int plane = blockIdx.y;
     const int col0 = blockIdx.x * tc;
     const int ncol = min(tc, Wf - col0);
@@ -316,7 +378,7 @@ __global__ __launch_bounds__(NT) void fft_cols_kernel(ColArgs a, Plan p) {
         A[idx] = v;
     }
     float2* Z = A;
-    if (MODE != COL_INV_POLAR) Z = fft_run<false>(A, Bf, p, tc, 1, tc, true);
+    if (MODE != COL_INV_POLAR) Z = fft_run<false, BIG>(A, Bf, p, twl, tc, 1, tc, true);
     float2* other = (Z == A) ? Bf : A;
 
     if (MODE == COL_FWD) {
@@ -355,19 +417,25 @@ __global__ __launch_bounds__(NT) void fft_cols_kernel(ColArgs a, Plan p) {
             Z[idx] = cmul(r, make_float2(A_ * cs, -A_ * sn));           // |z| A e^{i(ang z - ph)}  :413-417
         }
     }
-    float2* Y = fft_run<true>(Z, other, p, tc, 1, tc, true);
+    float2* Y = fft_run<true, BIG>(Z, other, p, twl, tc, 1, tc, true);
     for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
         const int h = idx / tc, c = idx - h * tc;
         if (c < ncol) zp[(long)h * Wf + col0 + c] = Y[idx];
     }
 }
 
+bool plan_big(const Plan& p) {
+    for (int i = 0; i < p.nst; ++i)
+        if (p.radix[i] == 17 || p.radix[i] == 23) return true;
+    return false;
+}
+
 int pick_tc(int H) {
     const long per_col = 2L * H * sizeof(float2);
-    if (per_col * 16 <= 64 * 1024) return 16;
-    if (per_col * 8 <= 150 * 1024) return 8;
-    if (per_col * 4 <= 150 * 1024) return 4;
-    if (per_col * 2 <= 150 * 1024) return 2;
+    if (per_col * 16 <= 56 * 1024) return 16;
+    if (per_col * 8 <= 140 * 1024) return 8;
+    if (per_col * 4 <= 140 * 1024) return 4;
+    if (per_col * 2 <= 140 * 1024) return 2;
     return 0;
 }
 
@@ -394,12 +462,17 @@ int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
     if (!make_plan(a.H, a.H, &p)) return FDN_ERR_UNSUPPORTED;
     a.tc = pick_tc(a.H);
     if (a.tc == 0 || planes > 65535 * 32L) return FDN_ERR_UNSUPPORTED;
-    const size_t lds = 2UL * a.H * a.tc * sizeof(float2);
-    if (int e = set_lds(fft_cols_kernel<MODE>, lds)) return e;
-    // planes on grid.y (<= 65535): fold if needed
+    const size_t lds = (2UL * a.H * a.tc + a.H) * sizeof(float2);
     if (planes > 65535) return FDN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(fft_cols_kernel<MODE>, dim3(cdiv(a.Wf, a.tc), (unsigned)planes), dim3(NT), lds,
-                       static_cast<hipStream_t>(stream), a, p);
+    if (plan_big(p)) {
+        if (int e = set_lds(fft_cols_kernel<MODE, true>, lds)) return e;
+        hipLaunchKernelGGL((fft_cols_kernel<MODE, true>), dim3(cdiv(a.Wf, a.tc), (unsigned)planes), dim3(NT), lds,
+                           static_cast<hipStream_t>(stream), a, p);
+    } else {
+        if (int e = set_lds(fft_cols_kernel<MODE, false>, lds)) return e;
+        hipLaunchKernelGGL((fft_cols_kernel<MODE, false>), dim3(cdiv(a.Wf, a.tc), (unsigned)planes), dim3(NT), lds,
+                           static_cast<hipStream_t>(stream), a, p);
+    }
     return fdn_launch_status();
 }
 
@@ -415,11 +488,17 @@ extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fd
     Plan p;
     if (!make_plan(W / 2, W, &p)) return FDN_ERR_UNSUPPORTED;
     const int rpb = pick_rpb(W / 2);
-    const size_t lds = 2UL * rpb * (W / 2) * sizeof(float2);
+    const size_t lds = (2UL * rpb * (W / 2) + W) * sizeof(float2);
     if (lds > 160 * 1024) return FDN_ERR_UNSUPPORTED;
-    if (int e = set_lds(rfft_rows_kernel, lds)) return e;
-    hipLaunchKernelGGL(rfft_rows_kernel, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream), in,
-                       reinterpret_cast<float2*>(out_c), W, rows, rpb, p);
+    if (plan_big(p)) {
+        if (int e = set_lds(rfft_rows_kernel<true>, lds)) return e;
+        hipLaunchKernelGGL(rfft_rows_kernel<true>, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream), in,
+                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p);
+    } else {
+        if (int e = set_lds(rfft_rows_kernel<false>, lds)) return e;
+        hipLaunchKernelGGL(rfft_rows_kernel<false>, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream), in,
+                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p);
+    }
     return fdn_launch_status();
 }
 
@@ -429,13 +508,20 @@ extern "C" int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane
     Plan p;
     if (!make_plan(W / 2, W, &p)) return FDN_ERR_UNSUPPORTED;
     const int rpb = pick_rpb(W / 2);
-    const size_t lds = 2UL * rpb * (W / 2) * sizeof(float2);
+    const size_t lds = (2UL * rpb * (W / 2) + W) * sizeof(float2);
     if (lds > 160 * 1024) return FDN_ERR_UNSUPPORTED;
-    if (int e = set_lds(irfft_rows_kernel, lds)) return e;
     const long rows = planes * H;
-    hipLaunchKernelGGL(irfft_rows_kernel, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float2*>(in_c), in_row_bins, (long)H, in_plane_bins, out, W, H, rows, rpb, scale,
-                       res, alpha, p);
+    if (plan_big(p)) {
+        if (int e = set_lds(irfft_rows_kernel<true>, lds)) return e;
+        hipLaunchKernelGGL(irfft_rows_kernel<true>, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream),
+                           reinterpret_cast<const float2*>(in_c), in_row_bins, (long)H, in_plane_bins, out, W, H, rows, rpb,
+                           scale, res, alpha, p);
+    } else {
+        if (int e = set_lds(irfft_rows_kernel<false>, lds)) return e;
+        hipLaunchKernelGGL(irfft_rows_kernel<false>, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream),
+                           reinterpret_cast<const float2*>(in_c), in_row_bins, (long)H, in_plane_bins, out, W, H, rows, rpb,
+                           scale, res, alpha, p);
+    }
     return fdn_launch_status();
 }
 
