@@ -52,31 +52,45 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ x,
     }
 }
 
+// One workgroup produces the output pair (2m, 2m+1): both read input channel m for the GELU
+// branch, and (C+2m)/2, (C+2m+1)/2 for the gate branch (the same channel when C is even), so every
+// input plane is read once instead of twice.
 __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       float* __restrict__ out, int C, int H, int W, int tiles_x) {
     __shared__ float ta[TH + 2][LS];
-    __shared__ float tb[TH + 2][LS];
-    const int j = blockIdx.y, b = blockIdx.z;
-    const int ca = j >> 1, cb = (C + j) >> 1;     // grouped conv: output o reads input o/2
+    __shared__ float tb[2][TH + 2][LS];
+    const int m = blockIdx.y, b = blockIdx.z;
+    const int j0 = 2 * m, j1 = 2 * m + 1;
+    const bool has1 = j1 < C;
+    const int cb0 = (C + j0) >> 1, cb1 = (C + j1) >> 1;     // grouped conv: output o reads input o/2
+    const bool same = cb1 == cb0 || !has1;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const long hw = (long)H * W;
-    load_halo(ta, x + ((long)b * C + ca) * hw, H, W, ty0, tx0);
-    load_halo(tb, x + ((long)b * C + cb) * hw, H, W, ty0, tx0);
-    float wa[9], wb[9];
+    load_halo(ta, x + ((long)b * C + m) * hw, H, W, ty0, tx0);
+    load_halo(tb[0], x + ((long)b * C + cb0) * hw, H, W, ty0, tx0);
+    if (!same) load_halo(tb[1], x + ((long)b * C + cb1) * hw, H, W, ty0, tx0);
+    float wa0[9], wb0[9], wa1[9], wb1[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        wa[i] = w[j * 9 + i];
-        wb[i] = w[(C + j) * 9 + i];
+        wa0[i] = w[j0 * 9 + i];
+        wb0[i] = w[(C + j0) * 9 + i];
+        wa1[i] = has1 ? w[j1 * 9 + i] : 0.f;
+        wb1[i] = has1 ? w[(C + j1) * 9 + i] : 0.f;
     }
     __syncthreads();
     const int cx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
     const int gx = tx0 + cx;
     if (gx >= W) return;
-    float* dst = out + ((long)b * C + j) * hw;
+    float* d0 = out + ((long)b * C + j0) * hw;
+    float* d1 = out + ((long)b * C + j1) * hw;
+    const float (*t1)[LS] = same ? tb[0] : tb[1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int gy = ty0 + r0 + i;
-        if (gy < H) dst[(long)gy * W + gx] = gelu_erf(stencil(ta, r0 + i, cx, wa)) * stencil(tb, r0 + i, cx, wb);
+        if (gy < H) {
+            d0[(long)gy * W + gx] = gelu_fast(stencil(ta, r0 + i, cx, wa0)) * stencil(tb[0], r0 + i, cx, wb0);
+            if (has1) d1[(long)gy * W + gx] = gelu_fast(stencil(ta, r0 + i, cx, wa1)) * stencil(t1, r0 + i, cx, wb1);
+        }
     }
 }
 
@@ -136,7 +150,7 @@ extern "C" int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, 
 extern "C" int fdn_dwconv_gate(const float* x, const float* w, float* out, int B, int C, int H, int W, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w && out && B > 0 && C > 0 && H > 0 && W > 0 && C < 65536 && B < 65536);
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
-    hipLaunchKernelGGL(dw_gate_kernel, dim3(tx * ty, C, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, out, C, H,
+    hipLaunchKernelGGL(dw_gate_kernel, dim3(tx * ty, (C + 1) / 2, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, out, C, H,
                        W, tx);
     return fdn_launch_status();
 }

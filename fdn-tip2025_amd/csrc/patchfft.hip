@@ -1,10 +1,13 @@
 // 8x8-patch spectral kernels: the "one launch per block" fused FFT <-> pointwise <-> iFFT of the
 // FDformer (FDSA core and FDFFN middle).  Everything between the global load of the activation
 // tile and the global store of the result stays in LDS / registers:
-//   depthwise 3x3 (halo tile) -> rfft2 per 8x8 patch (8-point radix-2 butterflies in registers,
-//   row pass then column pass through LDS) -> amplitude/phase recombination without atan2/sincos
-//   (e^{i(ang q - ang k)} = u_q * conj(u_k), e^{i ang v} = v/|v|) -> irfft2.
-// Tile = 32 x 64 pixels (4 x 8 patches) of one channel per 256-thread workgroup.
+//   depthwise 3x3 (halo tile) -> rfft2 per 8x8 patch (real 8-point transforms via a 4-point
+//   complex FFT in registers, row pass then column pass through LDS) -> amplitude/phase
+//   recombination without atan2/sincos (e^{i(ang q - ang k)} = u_q * conj(u_k), e^{i ang v} = v/|v|;
+//   SURVEY.md App. C; v_rsq_f32 for the normalisations) -> irfft2 -> 32-byte row-segment stores.
+// Tile = 32 x 64 pixels (4 x 8 patches) of one channel per 256-thread workgroup; thread = (patch,
+// row) computes its own 8 stencil outputs and feeds them straight into the row transform, so the
+// only LDS traffic is the halo tile (one channel at a time, double buffered) and the spectra.
 #include "common.hpp"
 
 namespace {
@@ -12,37 +15,31 @@ namespace {
 constexpr int TH = 32, TW = 64;
 constexpr int NP = 32;             // patches per tile
 constexpr int PS = 41;             // patch stride of the spectrum buffer in float2 (40 used + 1 pad)
+constexpr float C8 = 0.70710678118654752440f;
 
 // in-place 8-point complex FFT, natural order in and out.  INV: e^{+...}, unscaled.
 template <bool INV>
 __device__ __forceinline__ void fft8(float2 (&v)[8]) {
     constexpr float S = INV ? 1.f : -1.f;
-    constexpr float C8 = 0.70710678118654752440f;
-    // stage 1 (span 4), twiddle w8^i
     float2 a[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         a[i] = make_float2(v[i].x + v[i + 4].x, v[i].y + v[i + 4].y);
         const float2 d = make_float2(v[i].x - v[i + 4].x, v[i].y - v[i + 4].y);
-        float2 w;
-        if (i == 0) w = make_float2(1.f, 0.f);
-        else if (i == 1) w = make_float2(C8, S * C8);
-        else if (i == 2) w = make_float2(0.f, S);
-        else w = make_float2(-C8, S * C8);
-        a[i + 4] = cmul(d, w);
+        if (i == 0) a[4] = d;
+        else if (i == 1) a[5] = make_float2(C8 * (d.x - S * d.y), C8 * (S * d.x + d.y));
+        else if (i == 2) a[6] = make_float2(-S * d.y, S * d.x);
+        else a[7] = make_float2(-C8 * (d.x + S * d.y), C8 * (S * d.x - d.y));
     }
-    // stage 2 (span 2), twiddle w4^i
     float2 c[8];
 #pragma unroll
     for (int h = 0; h < 8; h += 4) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            c[h + i] = make_float2(a[h + i].x + a[h + i + 2].x, a[h + i].y + a[h + i + 2].y);
-            const float2 d = make_float2(a[h + i].x - a[h + i + 2].x, a[h + i].y - a[h + i + 2].y);
-            c[h + i + 2] = (i == 0) ? d : cmul(d, make_float2(0.f, S));
-        }
+        c[h] = make_float2(a[h].x + a[h + 2].x, a[h].y + a[h + 2].y);
+        c[h + 2] = make_float2(a[h].x - a[h + 2].x, a[h].y - a[h + 2].y);
+        c[h + 1] = make_float2(a[h + 1].x + a[h + 3].x, a[h + 1].y + a[h + 3].y);
+        const float2 d = make_float2(a[h + 1].x - a[h + 3].x, a[h + 1].y - a[h + 3].y);
+        c[h + 3] = make_float2(-S * d.y, S * d.x);
     }
-    // stage 3 (span 1) and bit-reversed write-back
     constexpr int br[8] = {0, 4, 2, 6, 1, 5, 3, 7};
 #pragma unroll
     for (int h = 0; h < 8; h += 2) {
@@ -51,108 +48,144 @@ __device__ __forceinline__ void fft8(float2 (&v)[8]) {
     }
 }
 
-// forward real row transform: 8 reals -> bins 0..4
-__device__ __forceinline__ void rfft8_row(const float* r, float2 (&o)[5]) {
-    float2 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = make_float2(r[i], 0.f);
-    fft8<false>(v);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) o[i] = v[i];
-}
-
-// inverse c2r row transform from bins 0..4 (imag of bins 0 and 4 ignored, like pocketfft/MKL c2r)
-__device__ __forceinline__ void irfft8_row(const float2 (&x)[5], float* r) {
-    float2 v[8];
-    v[0] = make_float2(x[0].x, 0.f);
-    v[4] = make_float2(x[4].x, 0.f);
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {
-        v[i] = x[i];
-        v[8 - i] = make_float2(x[i].x, -x[i].y);
+// forward real row transform: 8 reals -> bins 0..4, through one 4-point complex FFT of
+// z[n] = x[2n] + i x[2n+1] and the split  X[k] = E[k] + W8^k O[k]
+__device__ __forceinline__ void rfft8_row(const float (&x)[8], float2 (&o)[5]) {
+    const float2 z0 = make_float2(x[0], x[1]), z1 = make_float2(x[2], x[3]);
+    const float2 z2 = make_float2(x[4], x[5]), z3 = make_float2(x[6], x[7]);
+    const float2 s02 = make_float2(z0.x + z2.x, z0.y + z2.y), d02 = make_float2(z0.x - z2.x, z0.y - z2.y);
+    const float2 s13 = make_float2(z1.x + z3.x, z1.y + z3.y), d13 = make_float2(z1.x - z3.x, z1.y - z3.y);
+    const float2 Z0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+    const float2 Z2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+    const float2 Z1 = make_float2(d02.x + d13.y, d02.y - d13.x);     // d02 - i d13
+    const float2 Z3 = make_float2(d02.x - d13.y, d02.y + d13.x);     // d02 + i d13
+    o[0] = make_float2(Z0.x + Z0.y, 0.f);
+    o[4] = make_float2(Z0.x - Z0.y, 0.f);
+    o[2] = make_float2(Z2.x, -Z2.y);
+    // k = 1: E = (Z1 + conj Z3)/2, D = (Z1 - conj Z3)/2, O = -i D, X1 = E + W8 O, W8 = (c, -c)
+    {
+        const float2 e = make_float2(0.5f * (Z1.x + Z3.x), 0.5f * (Z1.y - Z3.y));
+        const float2 d = make_float2(0.5f * (Z1.x - Z3.x), 0.5f * (Z1.y + Z3.y));
+        const float2 oo = make_float2(d.y, -d.x);
+        o[1] = make_float2(e.x + C8 * (oo.x + oo.y), e.y + C8 * (oo.y - oo.x));
+        // k = 3: E3 = conj E, O3 = conj O, W8^3 = (-c, -c)
+        const float2 e3 = make_float2(e.x, -e.y), o3 = make_float2(oo.x, -oo.y);
+        o[3] = make_float2(e3.x + C8 * (-o3.x + o3.y), e3.y + C8 * (-o3.x - o3.y));
     }
-    fft8<true>(v);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = v[i].x;
 }
 
-__device__ __forceinline__ float2 unit(float2 z) {
-    const float n = 1.0f / cabs2(z);
-    return make_float2(z.x * n, z.y * n);
+// inverse c2r row transform from bins 0..4 (imag of bins 0 and 4 ignored, like pocketfft/MKL c2r),
+// unscaled: returns 8 * x, through one 4-point complex inverse FFT
+__device__ __forceinline__ void irfft8_row(const float2 (&X)[5], float (&x)[8]) {
+    const float2 Z0 = make_float2(X[0].x + X[4].x, X[0].x - X[4].x);
+    const float2 Z2 = make_float2(2.f * X[2].x, -2.f * X[2].y);
+    // k = 1: E' = X1 + conj X3, D' = X1 - conj X3, O' = D' * (c, c), Z1 = E' + i O'
+    const float2 e1 = make_float2(X[1].x + X[3].x, X[1].y - X[3].y);
+    const float2 d1 = make_float2(X[1].x - X[3].x, X[1].y + X[3].y);
+    const float2 o1 = make_float2(C8 * (d1.x - d1.y), C8 * (d1.x + d1.y));
+    const float2 Z1 = make_float2(e1.x - o1.y, e1.y + o1.x);
+    // k = 3: E' = conj e1, D' = -conj d1, O' = D' * (-c, c), Z3 = E' + i O'
+    const float2 e3 = make_float2(e1.x, -e1.y);
+    const float2 d3 = make_float2(-d1.x, d1.y);
+    const float2 o3 = make_float2(C8 * (-d3.x - d3.y), C8 * (d3.x - d3.y));
+    const float2 Z3 = make_float2(e3.x - o3.y, e3.y + o3.x);
+    const float2 s02 = make_float2(Z0.x + Z2.x, Z0.y + Z2.y), d02 = make_float2(Z0.x - Z2.x, Z0.y - Z2.y);
+    const float2 s13 = make_float2(Z1.x + Z3.x, Z1.y + Z3.y), d13 = make_float2(Z1.x - Z3.x, Z1.y - Z3.y);
+    const float2 z0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+    const float2 z2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+    const float2 z1 = make_float2(d02.x - d13.y, d02.y + d13.x);     // d02 + i d13
+    const float2 z3 = make_float2(d02.x + d13.y, d02.y - d13.x);     // d02 - i d13
+    x[0] = z0.x; x[1] = z0.y; x[2] = z1.x; x[3] = z1.y; x[4] = z2.x; x[5] = z2.y; x[6] = z3.x; x[7] = z3.y;
+}
+
+__device__ __forceinline__ float rsq(float v) { return __builtin_amdgcn_rsqf(v); }
+
+// ------------------------------------------------------------------------------------------
+// halo tiles: (TH+2) x (TW+2) floats of one plane, row stride HS (odd: thread (patch,row) reads hit
+// distinct banks); loaded through registers so the next channel's loads fly during the transforms
+// ------------------------------------------------------------------------------------------
+constexpr int HS = 65 + 2;         // 67: (r*67 + 8*px) mod 32 distinct for r<8, px<4
+constexpr int HALO = (TH + 2) * (TW + 2);
+constexpr int HPT = (HALO + 255) / 256;   // 9 elements per thread
+
+__device__ __forceinline__ void halo_fetch(const float* __restrict__ src, int H, int W, int y0, int x0, float (&r)[HPT]) {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int rr = idx / (TW + 2), cc = idx - rr * (TW + 2);
+        const int y = y0 - 1 + rr, x = x0 - 1 + cc;
+        r[i] = (idx < HALO && y >= 0 && y < H && x >= 0 && x < W) ? src[(long)y * W + x] : 0.f;
+    }
+}
+__device__ __forceinline__ void halo_stash(float* t, const float (&r)[HPT]) {
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int rr = idx / (TW + 2), cc = idx - rr * (TW + 2);
+        if (idx < HALO) t[rr * HS + cc] = r[i];
+    }
+}
+// 3x3 stencil for the 8 pixels of row `row`, columns col0..col0+7 of the tile (halo origin -1,-1)
+__device__ __forceinline__ void stencil_row8(const float* t, int row, int col0, const float (&w)[9], float (&o)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = t[(row + dy) * HS + col0 + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) o[j] = fmaf(w[dy * 3 + dx], v[j + dx], o[j]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // FDSA core
 // ------------------------------------------------------------------------------------------
-constexpr int LS = 68;
-
-__global__ __launch_bounds__(256) void fdsa_core_kernel(const float* __restrict__ hidden, const float* __restrict__ dww,
-                                                        const float* __restrict__ fftw, float* __restrict__ out, int E,
-                                                        int H, int W, int tiles_x) {
-    // tin (halo tiles of q,k,v,vv) is dead once the stencils are done; the spectra alias it.
-    __shared__ __attribute__((aligned(16))) float tin_raw[4 * (TH + 2) * LS];
-    __shared__ __attribute__((aligned(16))) float D[3][TH][LS];
-    float (*tin)[TH + 2][LS] = reinterpret_cast<float (*)[TH + 2][LS]>(tin_raw);
-    float2* S = reinterpret_cast<float2*>(tin_raw);   // [3][NP][PS]  (3*32*41*8 B = 31.5 KB <= 37 KB)
-    static_assert(3 * NP * PS * 8 <= 4 * (TH + 2) * LS * 4, "spectrum buffer must fit in the halo buffer");
+__global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restrict__ hidden, const float* __restrict__ dww,
+                                                           const float* __restrict__ fftw, float* __restrict__ out, int E,
+                                                           int H, int W, int tiles_x) {
+    __shared__ float halo[2][(TH + 2) * HS];
+    __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
 
     const int tid = threadIdx.x;
     const int e = blockIdx.y, b = blockIdx.z;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const long hw = (long)H * W;
     const long base = (long)b * 4 * E * hw;
-
-    for (int t = 0; t < 4; ++t) {
-        const float* src = hidden + base + (long)(t * E + e) * hw;
-        for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
-            const int r = i / (TW + 2), c = i - r * (TW + 2);
-            const int y = ty0 - 1 + r, x = tx0 - 1 + c;
-            tin[t][r][c] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(long)y * W + x] : 0.f;
-        }
-    }
-    __syncthreads();
-
-    // ---- depthwise 3x3 (to_hidden_dw, FDN_arch.py:578) ------------------------------------
-    {
-        const int cx = tid & 63, r0 = (tid >> 6) * 8;
-        const int gx = tx0 + cx;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float wk[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) wk[i] = dww[(t * E + e) * 9 + i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float a = 0.f;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) a = fmaf(wk[dy * 3 + dx], tin[t][r0 + i + dy][cx + dx], a);
-                if (t < 3) D[t][r0 + i][cx] = a;
-                else {
-                    const int gy = ty0 + r0 + i;
-                    if (gy < H && gx < W) out[base + (long)(3 * E + e) * hw + (long)gy * W + gx] = a;   // v_value
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- forward rows: thread = (patch, row) ------------------------------------------------
     const int patch = tid >> 3, rr = tid & 7;
     const int py = patch >> 3, px = patch & 7;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        float r[8];
-        const float4 lo = *reinterpret_cast<const float4*>(&D[t][py * 8 + rr][px * 8]);
-        const float4 hi = *reinterpret_cast<const float4*>(&D[t][py * 8 + rr][px * 8 + 4]);
-        r[0] = lo.x; r[1] = lo.y; r[2] = lo.z; r[3] = lo.w; r[4] = hi.x; r[5] = hi.y; r[6] = hi.z; r[7] = hi.w;
-        float2 o[5];
-        rfft8_row(r, o);
-#pragma unroll
-        for (int kx = 0; kx < 5; ++kx) S[(t * NP + patch) * PS + kx * 8 + rr] = o[kx];
-    }
+    const int gy = ty0 + py * 8 + rr, gx = tx0 + px * 8;
+    const bool inside = gy < H && gx < W;          // patches are entirely inside or outside (H, W % 8 == 0)
+
+    float pre[HPT];
+    halo_fetch(hidden + base + (long)e * hw, H, W, ty0, tx0, pre);
+    halo_stash(halo[0], pre);
     __syncthreads();
+
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < 3) halo_fetch(hidden + base + (long)((t + 1) * E + e) * hw, H, W, ty0, tx0, pre);
+        float wk[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wk[i] = dww[(t * E + e) * 9 + i];
+        float o8[8];
+        stencil_row8(halo[t & 1], py * 8 + rr, px * 8, wk, o8);          // to_hidden_dw, FDN_arch.py:578
+        if (t < 3) {
+            float2 sp[5];
+            rfft8_row(o8, sp);
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) S[(t * NP + patch) * PS + kx * 8 + rr] = sp[kx];
+            halo_stash(halo[(t + 1) & 1], pre);
+        } else if (inside) {                                                // v_value goes straight out
+            float* dst = out + base + (long)(3 * E + e) * hw + (long)gy * W + gx;
+            *reinterpret_cast<float4*>(dst) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+        }
+        __syncthreads();
+    }
 
     // ---- columns: thread = (patch, kx): forward, recombine, inverse ---------------------------
     if (tid < NP * 5) {
@@ -174,13 +207,16 @@ __global__ __launch_bounds__(256) void fdsa_core_kernel(const float* __restrict_
             const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));            // :591-593
             float2 qk = cmul(q[ky], k[ky]);                                               // :595
             qk = make_float2(rd1(qk.x), rd1(qk.y));                                       // :597
-            const float qka = cabs2(qk), va = cabs2(v1);                                  // :599,601
-            const float2 uq = unit(make_float2(rd1(q[ky].x), rd1(q[ky].y)));              // :603,605
-            const float2 uk = unit(make_float2(rd1(k[ky].x), rd1(k[ky].y)));              // :604,606
-            const float2 u = cmulc(uq, uk);                                               // e^{i(qp-kp)} :607
-            const float2 uv = make_float2(v1.x / va, v1.y / va);                          // e^{i v_p}
+            const float qk2 = qk.x * qk.x + qk.y * qk.y, v2 = v1.x * v1.x + v1.y * v1.y;
+            const float qka = qk2 * rsq(qk2);                                             // |qk|  :599
+            const float iv = rsq(v2), va = v2 * iv;                                       // |v|   :601
+            const float2 qr = make_float2(rd1(q[ky].x), rd1(q[ky].y));                    // :603
+            const float2 kr = make_float2(rd1(k[ky].x), rd1(k[ky].y));                    // :604
+            const float nq = rsq(qr.x * qr.x + qr.y * qr.y), nk = rsq(kr.x * kr.x + kr.y * kr.y);
+            float2 u = cmulc(make_float2(qr.x * nq, qr.y * nq), make_float2(kr.x * nk, kr.y * nk));   // e^{i(qp-kp)} :605-607
+            const float g = qka * iv;
             o1[ky] = make_float2(va * u.x, va * u.y);                                     // :609-612
-            o2[ky] = make_float2(qka * uv.x, qka * uv.y);                                 // :617-619
+            o2[ky] = make_float2(g * v1.x, g * v1.y);                                     // qka e^{i v_p} :617-619
             o3[ky] = make_float2(qka * u.x, qka * u.y);                                   // :627-629
         }
         fft8<true>(o1);
@@ -196,31 +232,18 @@ __global__ __launch_bounds__(256) void fdsa_core_kernel(const float* __restrict_
     }
     __syncthreads();
 
-    // ---- inverse rows -> D ----------------------------------------------------------------------
+    // ---- inverse rows, 32-byte segments straight to global (out1|out2|out3) --------------------------
+    if (inside) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        float2 x[5];
+        for (int t = 0; t < 3; ++t) {
+            float2 x[5];
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) x[kx] = S[(t * NP + patch) * PS + kx * 8 + rr];
-        float r[8];
-        irfft8_row(x, r);
-        *reinterpret_cast<float4*>(&D[t][py * 8 + rr][px * 8]) = make_float4(r[0], r[1], r[2], r[3]);
-        *reinterpret_cast<float4*>(&D[t][py * 8 + rr][px * 8 + 4]) = make_float4(r[4], r[5], r[6], r[7]);
-    }
-    __syncthreads();
-
-    // ---- coalesced store of out1|out2|out3 -------------------------------------------------------
-    {
-        const int cx = tid & 63, r0 = (tid >> 6) * 8;
-        const int gx = tx0 + cx;
-        if (gx < W) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int gy = ty0 + r0 + i;
-                    if (gy < H) out[base + (long)(t * E + e) * hw + (long)gy * W + gx] = D[t][r0 + i][cx];
-                }
+            for (int kx = 0; kx < 5; ++kx) x[kx] = S[(t * NP + patch) * PS + kx * 8 + rr];
+            float r[8];
+            irfft8_row(x, r);
+            float* dst = out + base + (long)(t * E + e) * hw + (long)gy * W + gx;
+            *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(r[4], r[5], r[6], r[7]);
         }
     }
 }
@@ -229,15 +252,16 @@ __global__ __launch_bounds__(256) void fdsa_core_kernel(const float* __restrict_
 // FDFFN middle: freq branch + (dw3x3 -> GELU -> dw3x3) spatial branch
 // ------------------------------------------------------------------------------------------
 constexpr int LS2 = 72;
+constexpr int LSM = 67;
 
-__global__ __launch_bounds__(256) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
-                                                        const float* __restrict__ w2, const float* __restrict__ ffta,
-                                                        const float* __restrict__ fftp, float* __restrict__ out, int Hd,
-                                                        int H, int W, int tiles_x) {
-    __shared__ __attribute__((aligned(16))) float tin[TH + 4][LS2];   // halo 2
-    __shared__ float mid[TH + 2][LS];                                  // gelu(dw0(x)) on halo 1
-    __shared__ __attribute__((aligned(16))) float Fq[TH][LS];          // frequency-branch result
-    __shared__ float2 S[NP * PS];
+__global__ __launch_bounds__(256, 4) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+                                                           const float* __restrict__ w2, const float* __restrict__ ffta,
+                                                           const float* __restrict__ fftp, float* __restrict__ out, int Hd,
+                                                           int H, int W, int tiles_x) {
+    __shared__ float tin[(TH + 4) * LS2];           // halo 2
+    __shared__ float mid[(TH + 2) * LSM];           // gelu(dw0(x)) on halo 1
+    __shared__ __attribute__((aligned(16))) float2 S[NP * PS];
+    __shared__ float2 filt[40];                     // ffta * e^{-i fftp} per (ky, kx)
 
     const int tid = threadIdx.x;
     const int c = blockIdx.y, b = blockIdx.z;
@@ -248,7 +272,13 @@ __global__ __launch_bounds__(256) void fdffn_mid_kernel(const float* __restrict_
     for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
         const int r = i / (TW + 4), cc = i - r * (TW + 4);
         const int y = ty0 - 2 + r, xx = tx0 - 2 + cc;
-        tin[r][cc] = (y >= 0 && y < H && xx >= 0 && xx < W) ? src[(long)y * W + xx] : 0.f;
+        tin[r * LS2 + cc] = (y >= 0 && y < H && xx >= 0 && xx < W) ? src[(long)y * W + xx] : 0.f;
+    }
+    if (tid < 40) {
+        float sn, cs;
+        sincosf(fftp[c * 40 + tid], &sn, &cs);
+        const float a = ffta[c * 40 + tid];
+        filt[tid] = make_float2(a * cs, -a * sn);
     }
     float k0[9], k2[9];
 #pragma unroll
@@ -268,10 +298,10 @@ __global__ __launch_bounds__(256) void fdffn_mid_kernel(const float* __restrict_
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) a = fmaf(k0[dy * 3 + dx], tin[r + dy][cc + dx], a);
-            a = gelu_erf(a);
+                for (int dx = 0; dx < 3; ++dx) a = fmaf(k0[dy * 3 + dx], tin[(r + dy) * LS2 + cc + dx], a);
+            a = gelu_fast(a);
         }
-        mid[r][cc] = a;
+        mid[r * LSM + cc] = a;
     }
 
     // forward rows of the frequency branch straight from the input tile (centre of tin)
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(256) void fdffn_mid_kernel(const float* __restrict_
     {
         float r[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = tin[2 + py * 8 + rr][2 + px * 8 + i];
+        for (int i = 0; i < 8; ++i) r[i] = tin[(2 + py * 8 + rr) * LS2 + 2 + px * 8 + i];
         float2 o[5];
         rfft8_row(r, o);
 #pragma unroll
@@ -288,18 +318,20 @@ __global__ __launch_bounds__(256) void fdffn_mid_kernel(const float* __restrict_
     }
     __syncthreads();
 
-    // second depthwise conv (kept in registers until the final add)
+    // second depthwise conv for this thread's row segment (kept in registers until the final add)
     float sp[8];
     {
-        const int cx = tid & 63, r0 = (tid >> 6) * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float a = 0.f;
+        for (int j = 0; j < 8; ++j) sp[j] = 0.f;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy) {
+            float v[10];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) a = fmaf(k2[dy * 3 + dx], mid[r0 + i + dy][cx + dx], a);
-            sp[i] = a;
+            for (int j = 0; j < 10; ++j) v[j] = mid[(py * 8 + rr + dy) * LSM + px * 8 + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) sp[j] = fmaf(k2[dy * 3 + dx], v[j + dx], sp[j]);
         }
     }
 
@@ -311,13 +343,8 @@ __global__ __launch_bounds__(256) void fdffn_mid_kernel(const float* __restrict_
         for (int i = 0; i < 8; ++i) z[i] = S[pj * PS + kx * 8 + i];
         fft8<false>(z);
 #pragma unroll
-        for (int ky = 0; ky < 8; ++ky) {
-            const float a = ffta[(c * 8 + ky) * 5 + kx], ph = fftp[(c * 8 + ky) * 5 + kx];
-            float sn, cs;
-            sincosf(ph, &sn, &cs);
-            const float2 zz = make_float2(rd1(z[ky].x), rd1(z[ky].y));                    // :461
-            z[ky] = cmul(zz, make_float2(a * cs, -a * sn));
-        }
+        for (int ky = 0; ky < 8; ++ky)
+            z[ky] = cmul(make_float2(rd1(z[ky].x), rd1(z[ky].y)), filt[ky * 5 + kx]);     // :461-468
         fft8<true>(z);
         constexpr float sc = 1.0f / 64.0f;
 #pragma unroll
@@ -326,26 +353,16 @@ __global__ __launch_bounds__(256) void fdffn_mid_kernel(const float* __restrict_
     __syncthreads();
 
     {
-        float2 xk[5];
+        const int gy = ty0 + py * 8 + rr, gx = tx0 + px * 8;
+        if (gy < H && gx < W) {
+            float2 xk[5];
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) xk[kx] = S[patch * PS + kx * 8 + rr];
-        float r[8];
-        irfft8_row(xk, r);
-        *reinterpret_cast<float4*>(&Fq[py * 8 + rr][px * 8]) = make_float4(r[0], r[1], r[2], r[3]);
-        *reinterpret_cast<float4*>(&Fq[py * 8 + rr][px * 8 + 4]) = make_float4(r[4], r[5], r[6], r[7]);
-    }
-    __syncthreads();
-
-    {
-        const int cx = tid & 63, r0 = (tid >> 6) * 8;
-        const int gx = tx0 + cx;
-        float* dst = out + ((long)b * Hd + c) * hw;
-        if (gx < W) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int gy = ty0 + r0 + i;
-                if (gy < H) dst[(long)gy * W + gx] = Fq[r0 + i][cx] + sp[i];               // :470
-            }
+            for (int kx = 0; kx < 5; ++kx) xk[kx] = S[patch * PS + kx * 8 + rr];
+            float r[8];
+            irfft8_row(xk, r);
+            float* dst = out + ((long)b * Hd + c) * hw + (long)gy * W + gx;
+            *reinterpret_cast<float4*>(dst) = make_float4(r[0] + sp[0], r[1] + sp[1], r[2] + sp[2], r[3] + sp[3]);   // :470
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(r[4] + sp[4], r[5] + sp[5], r[6] + sp[6], r[7] + sp[7]);
         }
     }
 }
@@ -356,6 +373,7 @@ extern "C" int fdn_fdsa_core(const float* hidden, const float* dw_w, const float
                              int W, fdn_stream_t stream) {
     FDN_CHECK_ARG(hidden && dw_w && fft_w && out && B > 0 && E > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0 && E < 65536 && B < 65536);
+    FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     hipLaunchKernelGGL(fdsa_core_kernel, dim3(tx * ty, E, B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
                        fft_w, out, E, H, W, tx);
@@ -366,6 +384,7 @@ extern "C" int fdn_fdffn_mid(const float* x, const float* w0, const float* w2, c
                              float* out, int B, int Hd, int H, int W, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w0 && w2 && ffta && fftp && out && B > 0 && Hd > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0 && Hd < 65536 && B < 65536);
+    FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     hipLaunchKernelGGL(fdffn_mid_kernel, dim3(tx * ty, Hd, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w0, w2,
                        ffta, fftp, out, Hd, H, W, tx);
