@@ -99,7 +99,8 @@ class FDSA(nn.Module):
         norms = (self.norm1, self.norm2, self.norm3)
         gam = self._c.get("g", [n.body.weight for n in norms], lambda: torch.cat([n.body.weight.detach() for n in norms]))
         bet = self._c.get("b", [n.body.bias for n in norms], lambda: torch.cat([n.body.bias.detach() for n in norms]))
-        return ops.conv1x1(o[:, :3 * e], _w(self.project_out.weight), ln3_gate=(stats, gam, bet, o[:, 3 * e:]), res=res)
+        return ops.conv1x1(o[:, :3 * e], _w(self.project_out.weight), ln3_gate=(stats, gam, bet, o[:, 3 * e:]), res=res,
+                           want_stats=res is not None)
 
     def forward(self, x):
         return self.fused(x)
@@ -127,7 +128,7 @@ class FDFFN(nn.Module):
         h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln)
         y = ops.fdffn_mid(h, _w(self.space[0].weight), _w(self.space[2].weight), _w(self.ffta), _w(self.fftp))
         g = ops.dwconv_gate(y, _w(self.dwconv.weight))
-        return ops.conv1x1(g, _w(self.project_out.weight), res=res)
+        return ops.conv1x1(g, _w(self.project_out.weight), res=res, want_stats=res is not None)
 
     def forward(self, x, x_high=None, xp2=None, x_img=None):
         return self.fused(x)
@@ -164,7 +165,7 @@ class FCAFFN(nn.Module):
         gam, bet = self.norm.params()
         t = ops.conv1x1(xi, _w(self.project_in.weight), ln_muladd=(stats, gam, bet, xn), muladd=(mul, add))
         g = ops.dwconv_gate(t, _w(self.dwconv.weight))
-        return ops.conv1x1(g, _w(self.project_out.weight), res=res)
+        return ops.conv1x1(g, _w(self.project_out.weight), res=res, want_stats=res is not None)
 
     def forward(self, x, x_high, xp2, x_img=None):
         return self.fused(x, x_high, xp2, x_img)
@@ -190,8 +191,8 @@ class TransformerBlock(nn.Module):
     def forward(self, xt):
         x, x_high, x_p, x_img = xt
         if self.att:
-            x = self.attn.fused(x, ln=(ops.chan_stats(x),) + self.norm1.params(), res=x)
-        x = self.ffn.fused(x, ln=(ops.chan_stats(x),) + self.norm2.params(), res=x)
+            x = self.attn.fused(x, ln=(ops.stats_of(x),) + self.norm1.params(), res=x)
+        x = self.ffn.fused(x, ln=(ops.stats_of(x),) + self.norm2.params(), res=x)
         if self.use_light:
             x = self.ffn2.fused(self.norm3(x), x_high, x_p, x_img, res=x)
         return x, x_high, x_p, x_img

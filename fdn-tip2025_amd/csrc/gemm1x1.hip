@@ -229,7 +229,34 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_kernel(fdn_conv1x1_desc d, Ge
                             if (d.epi == FDN_EPI_RES) v += bload(rr, voff, soff);
                             else if (d.epi == FDN_EPI_MULADD) v = v * bload(rm, voff, soff) + bload(rd, voff, soff);
                             bstore(v, ro, voff, soff);          // rows >= N fall outside the descriptor
+                            acc[m][r] = (nrow + 4 * kh < N) ? v : 0.f;
                         }
+                    if (d.stats_out && npass == 1) {
+                        // channel LayerNorm statistics of the tile just written (two-pass, registers only):
+                        // lane l and l^32 hold complementary rows of the same pixel
+                        float sm = 0.f;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sm += acc[m][r];
+                        sm += __shfl_xor(sm, 32);
+                        const float mean = sm / (float)N;
+                        float sq = 0.f;
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int n = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                                const float dlt = acc[m][r] - mean;
+                                sq += (n < N) ? dlt * dlt : 0.f;
+                            }
+                        sq += __shfl_xor(sq, 32);
+                        if (kh == 0) {
+                            float* sp = d.stats_out + (long)cur.b * 2 * P;
+                            sp[cur.pix] = mean;
+                            sp[P + cur.pix] = 1.0f / sqrtf(sq / (float)N + 1e-5f);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -323,6 +350,7 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
     if (d.pro == FDN_PRO_LN_MULADD) FDN_CHECK_ARG(d.xb);
     if (d.epi == FDN_EPI_RES) FDN_CHECK_ARG(d.res);
     if (d.epi == FDN_EPI_MULADD) FDN_CHECK_ARG(d.mul && d.add);
+    if (d.stats_out) FDN_CHECK_ARG(d.N <= 160);
     d.vec4 = 0;
     // 32-bit buffer offsets: every per-image plane set must stay below 4 GiB (incl. the padded K / N tails)
     {

@@ -29,7 +29,7 @@ class Conv1x1Desc(ctypes.Structure):
         ("stats", c_fp), ("gamma", c_fp), ("beta", c_fp), ("xb", c_fp), ("xbbs", ctypes.c_long),
         ("act", ctypes.c_int), ("epi", ctypes.c_int),
         ("res", c_fp), ("rbs", ctypes.c_long), ("mul", c_fp), ("add", c_fp), ("mbs", ctypes.c_long),
-        ("vec4", ctypes.c_int),
+        ("vec4", ctypes.c_int), ("stats_out", c_fp),
     ]
 
 

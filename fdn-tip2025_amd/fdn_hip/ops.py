@@ -34,8 +34,11 @@ def _flat(t, what):
 
 
 def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None, ln_muladd=None, res=None,
-            muladd=None):
+            muladd=None, want_stats=False):
     """1x1 conv with fused prologue/epilogue (fdn_conv1x1).
+
+    want_stats: also produce the channel-LayerNorm statistics of the output in the epilogue and attach
+    them to the returned tensor as `._fdn_stats` (consumed by `stats_of`).
 
     xs: tensor or list of <=3 tensors concatenated along channels.  w: [N, K] or [N, K, 1, 1].
     ln=(stats, gamma, beta) | ln3_gate=(stats, gamma[3E], beta[3E], vv) | ln_muladd=(stats, gamma, beta, x1)
@@ -80,8 +83,20 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
         d.mul, d.mbs = _planes(muladd[0], "mul")
         d.add, mbs2 = _planes(muladd[1], "add")
         assert mbs2 == d.mbs
+    stats = None
+    if want_stats and N <= 160:
+        stats = torch.empty((B, 1, 2, P), device=out.device, dtype=torch.float32)
+        d.stats_out = _flat(stats, "stats_out")
     check(lib().fdn_conv1x1(ctypes.byref(d), stream()), "fdn_conv1x1")
+    if want_stats:
+        out._fdn_stats = stats if stats is not None else chan_stats(out)   # LayerNorm statistics travel with the tensor
     return out
+
+
+def stats_of(x):
+    """LayerNorm statistics of x: reuse the ones its producer attached, else compute them."""
+    st = getattr(x, "_fdn_stats", None)
+    return st if st is not None else chan_stats(x)
 
 
 def chan_stats(x, groups=1):

@@ -68,6 +68,8 @@ typedef struct fdn_conv1x1_desc {
     const float* add;
     long mbs;
     int vec4; /* set by the library */
+    float* stats_out; /* optional [B][1][2][P]: (mean, rstd) over the N output channels of `out` (needs N <= 160):
+                         the LayerNorm statistics the NEXT block needs, produced in this epilogue */
 } fdn_conv1x1_desc;
 int fdn_conv1x1(const fdn_conv1x1_desc* d, fdn_stream_t stream);
 
