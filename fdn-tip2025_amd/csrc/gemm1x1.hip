@@ -278,6 +278,128 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_kernel(fdn_conv1x1_desc d, Ge
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-K variant (K <= 128, whole transposed weight matrix resident in LDS): the wave keeps its
+// 32-pixel activation strip for ALL K in registers (K/2 VGPRs), applies the prologue once, and then
+// walks the output-channel tiles one at a time: 16*NCH MFMAs into a single 16-register accumulator,
+// 16 stores, next tile.  Only 16 accumulator registers are live (5-6 waves per SIMD instead of 2),
+// the stores of tile m drain while tile m+1's MFMAs issue, and there is no pass loop and no barrier
+// after the weights are loaded.  Used for to_hidden / project_in (K = C) where N is 2.7-4.8 x K.
+// ------------------------------------------------------------------------------------------------
+template <int NCH, int PRO, int NW>
+__global__ __launch_bounds__(NW * 64) void conv1x1_smallk_kernel(fdn_conv1x1_desc d, Geo g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = NW * 64;
+    constexpr int Kp = NCH * KC;
+    const int K = d.K, N = d.N;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int ntiles = (N + 31) / 32;
+    const int NS = ntiles * 32 + 1;
+    float* tg = smem;
+    float* tb = smem + Kp;
+    float* Wl = smem + 2 * Kp;                 // [Kp][NS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+
+    for (int i = tid; i < Kp; i += NT) {
+        tg[i] = (PRO != FDN_PRO_NONE && i < K) ? d.gamma[i] : 0.f;
+        tb[i] = (PRO != FDN_PRO_NONE && i < K) ? d.beta[i] : 0.f;
+    }
+    // weights: W[n][k] (lanes along k) -> Wl[k][n]
+    for (int idx = tid; idx < Kp * ntiles * 32; idx += NT) {
+        const int k = idx % Kp, n = idx / Kp;
+        Wl[k * NS + n] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
+    }
+    __syncthreads();
+
+    const int ks0 = d.kseg[0], ks01 = d.kseg[0] + d.kseg[1];
+    struct Tile { int b; unsigned pix; bool ok; };
+    auto tile_setup = [&](int t) {
+        Tile r;
+        r.b = t / g.tiles_per_img;
+        const unsigned p_ = (unsigned)(t - r.b * g.tiles_per_img) * (NW * 32) + wave * 32 + ln;
+        r.ok = p_ < P;
+        r.pix = r.ok ? p_ : P - 1;
+        return r;
+    };
+    float xa[NCH * 16], xb[NCH * 16], yb[NCH * 16];
+    float mu_n = 0.f, rs_n = 0.f;
+    auto x_issue = [&](const Tile& t) {
+        const rsrc_t r0 = mk_rsrc(d.x[0] + (long)t.b * d.xbs[0], (unsigned)ks0 * P4);
+        const rsrc_t r1 = mk_rsrc(d.x[1] + (long)t.b * d.xbs[1], (unsigned)d.kseg[1] * P4);
+        const rsrc_t r2 = mk_rsrc(d.x[2] + (long)t.b * d.xbs[2], (unsigned)d.kseg[2] * P4);
+        const unsigned voff = (kh * P + t.pix) * 4u;
+#pragma unroll
+        for (int s = 0; s < NCH * 16; ++s) {
+            const int k = 2 * s;
+            if (k < ks0) xb[s] = bload(r0, voff, (unsigned)k * P4);
+            else if (k < ks01) xb[s] = bload(r1, voff, (unsigned)(k - ks0) * P4);
+            else xb[s] = bload(r2, voff, (unsigned)(k - ks01) * P4);
+        }
+        if (PRO == FDN_PRO_LN_MULADD) {
+            const rsrc_t ry = mk_rsrc(d.xb + (long)t.b * d.xbbs, (unsigned)K * P4);
+#pragma unroll
+            for (int s = 0; s < NCH * 16; ++s) yb[s] = bload(ry, voff, (unsigned)(2 * s) * P4);
+        }
+        if (PRO != FDN_PRO_NONE) {
+            const float* sp = d.stats + (long)t.b * 2 * P;
+            mu_n = sp[t.pix];
+            rs_n = sp[P + t.pix];
+        }
+    };
+
+    int tile = blockIdx.x;
+    bool live = tile < g.total_tiles;
+    Tile cur = tile_setup(live ? tile : 0);
+    if (live) x_issue(cur);
+    while (live) {
+        // take ownership of the prefetched strip, apply the prologue once
+#pragma unroll
+        for (int s = 0; s < NCH * 16; ++s) {
+            float v = xb[s];
+            if (PRO != FDN_PRO_NONE) {
+                const float ga = tg[2 * s + kh], be = tb[2 * s + kh];
+                v = (v - mu_n) * rs_n * ga + be;
+                if (PRO == FDN_PRO_LN_MULADD) v = v * yb[s] + yb[s];
+            }
+            xa[s] = v;
+        }
+        const int ntile = tile + gridDim.x;
+        const bool nlive = ntile < g.total_tiles;
+        const Tile nxt = tile_setup(nlive ? ntile : tile);
+        if (nlive) x_issue(nxt);                                   // lands while this tile's MFMAs run
+
+        const unsigned nb4 = (unsigned)N * P4;
+        const rsrc_t ro = mk_rsrc(d.out + (long)cur.b * d.obs, nb4);
+        const rsrc_t rr = mk_rsrc(d.res ? d.res + (long)cur.b * d.rbs : d.out, d.res ? nb4 : 0u);
+        const rsrc_t rm = mk_rsrc(d.mul ? d.mul + (long)cur.b * d.mbs : d.out, d.mul ? nb4 : 0u);
+        const rsrc_t rd = mk_rsrc(d.add ? d.add + (long)cur.b * d.mbs : d.out, d.add ? nb4 : 0u);
+        const unsigned voff = (4u * kh * P + cur.pix) * 4u;
+        for (int m = 0; m < ntiles; ++m) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* wcol = Wl + kh * NS + m * 32 + ln;
+#pragma unroll
+            for (int s = 0; s < NCH * 16; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[2 * s * NS], xa[s], acc, 0, 0, 0);
+            if (cur.ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                    const unsigned soff = (unsigned)nrow * P4;
+                    float v = acc[r];
+                    if (d.bias) { const int n = nrow + 4 * kh; v += (n < N) ? d.bias[n] : 0.f; }
+                    v = apply_act(v, d.act);
+                    if (d.epi == FDN_EPI_RES) v += bload(rr, voff, soff);
+                    else if (d.epi == FDN_EPI_MULADD) v = v * bload(rm, voff, soff) + bload(rd, voff, soff);
+                    bstore(v, ro, voff, soff);
+                }
+            }
+        }
+        cur = nxt; tile = ntile; live = nlive;
+    }
+}
+
 int pick_mt(int N) {
     // fewest computed 32-row tiles, then fewest passes; MT <= 5 keeps the accumulator at 80 VGPRs
     const int tiles = (N + 31) / 32;
@@ -324,6 +446,52 @@ int launch(const fdn_conv1x1_desc& d, hipStream_t s) {
     return fdn_launch_status();
 }
 
+template <int NCH, int PRO>
+int launch_smallk(const fdn_conv1x1_desc& d, hipStream_t s) {
+    const int ntiles = (d.N + 31) / 32;
+    const size_t lds = (2UL * NCH * KC + (size_t)NCH * KC * (ntiles * 32 + 1)) * sizeof(float);
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    constexpr int NW = 8;
+    Geo g;
+    g.resident = 1;
+    g.tiles_per_img = cdiv(d.P, NW * 32);
+    g.total_tiles = d.B * g.tiles_per_img;
+    auto kern = conv1x1_smallk_kernel<NCH, PRO, NW>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return FDN_ERR_LAUNCH;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 3) per_cu = 3;
+    if (per_cu < 1) per_cu = 1;
+    int grid = g_num_cu * per_cu;
+    if (grid > g.total_tiles) grid = g.total_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, d, g);
+    return fdn_launch_status();
+}
+
+// true when the small-K kernel covers this problem
+bool smallk_ok(const fdn_conv1x1_desc& d) {
+    if (d.K > 64 || d.stats_out || d.pro == FDN_PRO_LN3_GATE) return false;
+    if (d.N < 2 * d.K || d.N < 64) return false;                  // made for N >> K
+    const int nch = (d.K + KC - 1) / KC, ntiles = (d.N + 31) / 32;
+    const size_t lds = (2UL * nch * KC + (size_t)nch * KC * (ntiles * 32 + 1)) * sizeof(float);
+    return lds <= 100 * 1024;
+}
+
+template <int PRO>
+int launch_smallk_nch(const fdn_conv1x1_desc& d, hipStream_t s) {
+    const int nch = (d.K + KC - 1) / KC;
+    if (nch == 1) return launch_smallk<1, PRO>(d, s);
+    return launch_smallk<2, PRO>(d, s);
+}
+
 template <int MT>
 int launch_pro(const fdn_conv1x1_desc& d, hipStream_t s) {
     switch (d.pro) {
@@ -359,6 +527,13 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         if (d.kseg[1] > 0 && ((d.kseg[0] & 1) || (d.kseg[1] & 1))) return FDN_ERR_UNSUPPORTED;   // k-step pairs must not straddle segments
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (smallk_ok(d)) {
+        switch (d.pro) {
+            case FDN_PRO_NONE: return launch_smallk_nch<FDN_PRO_NONE>(d, s);
+            case FDN_PRO_LN: return launch_smallk_nch<FDN_PRO_LN>(d, s);
+            default: return launch_smallk_nch<FDN_PRO_LN_MULADD>(d, s);
+        }
+    }
     switch (pick_mt(d.N)) {
         case 1: return launch_pro<1>(d, s);
         case 2: return launch_pro<2>(d, s);
