@@ -251,10 +251,14 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------
 // FDFFN middle: freq branch + (dw3x3 -> GELU -> dw3x3) spatial branch
 // ------------------------------------------------------------------------------------------
-constexpr int LS2 = 72;
+constexpr int LS2 = 73;            // odd: lanes walking rows (ring) or (row, patch) pairs (row FFT) hit distinct banks
 constexpr int LSM = 67;
 
-__global__ __launch_bounds__(256, 4) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+constexpr int CPB = 4;                                  // channels per workgroup (software-pipelined)
+constexpr int HALO2 = (TH + 4) * (TW + 4);
+constexpr int HPT2 = (HALO2 + 255) / 256;               // 10 elements per thread
+
+__global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                            const float* __restrict__ w2, const float* __restrict__ ffta,
                                                            const float* __restrict__ fftp, float* __restrict__ out, int Hd,
                                                            int H, int W, int tiles_x) {
@@ -264,96 +268,141 @@ __global__ __launch_bounds__(256, 4) void fdffn_mid_kernel(const float* __restri
     __shared__ float2 filt[40];                     // ffta * e^{-i fftp} per (ky, kx)
 
     const int tid = threadIdx.x;
-    const int c = blockIdx.y, b = blockIdx.z;
+    const int cbase = blockIdx.y * CPB, b = blockIdx.z;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const long hw = (long)H * W;
-    const float* src = x + ((long)b * Hd + c) * hw;
-
-    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
-        const int r = i / (TW + 4), cc = i - r * (TW + 4);
-        const int y = ty0 - 2 + r, xx = tx0 - 2 + cc;
-        tin[r * LS2 + cc] = (y >= 0 && y < H && xx >= 0 && xx < W) ? src[(long)y * W + xx] : 0.f;
-    }
-    if (tid < 40) {
-        float sn, cs;
-        sincosf(fftp[c * 40 + tid], &sn, &cs);
-        const float a = ffta[c * 40 + tid];
-        filt[tid] = make_float2(a * cs, -a * sn);
-    }
-    float k0[9], k2[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        k0[i] = w0[c * 9 + i];
-        k2[i] = w2[c * 9 + i];
-    }
-    __syncthreads();
-
-    // first depthwise conv + GELU on the (TH+2) x (TW+2) ring; zero outside the image (= the
-    // zero padding the second conv sees, FDN_arch.py:439)
-    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
-        const int r = i / (TW + 2), cc = i - r * (TW + 2);
-        const int y = ty0 - 1 + r, xx = tx0 - 1 + cc;
-        float a = 0.f;
-        if (y >= 0 && y < H && xx >= 0 && xx < W) {
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) a = fmaf(k0[dy * 3 + dx], tin[(r + dy) * LS2 + cc + dx], a);
-            a = gelu_fast(a);
-        }
-        mid[r * LSM + cc] = a;
-    }
-
-    // forward rows of the frequency branch straight from the input tile (centre of tin)
     const int patch = tid >> 3, rr = tid & 7;
     const int py = patch >> 3, px = patch & 7;
-    {
-        float r[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = tin[(2 + py * 8 + rr) * LS2 + 2 + px * 8 + i];
-        float2 o[5];
-        rfft8_row(r, o);
-#pragma unroll
-        for (int kx = 0; kx < 5; ++kx) S[patch * PS + kx * 8 + rr] = o[kx];
-    }
-    __syncthreads();
+    const int gy = ty0 + py * 8 + rr, gx = tx0 + px * 8;
 
-    // second depthwise conv for this thread's row segment (kept in registers until the final add)
-    float sp[8];
-    {
+    float pre[HPT2];
+    auto fetch = [&](int c) {
+        const float* src = x + ((long)b * Hd + c) * hw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sp[j] = 0.f;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            float v[10];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) v[j] = mid[(py * 8 + rr + dy) * LSM + px * 8 + j];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) sp[j] = fmaf(k2[dy * 3 + dx], v[j + dx], sp[j]);
+        for (int i = 0; i < HPT2; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / (TW + 4), cc = idx - r * (TW + 4);
+            const int y = ty0 - 2 + r, xx = tx0 - 2 + cc;
+            pre[i] = (idx < HALO2 && y >= 0 && y < H && xx >= 0 && xx < W) ? src[(long)y * W + xx] : 0.f;
         }
-    }
-
-    // columns: forward, z * ffta * e^{-i fftp}, inverse  (FDN_arch.py:460-469)
-    if (tid < NP * 5) {
-        const int pj = tid / 5, kx = tid - pj * 5;
-        float2 z[8];
+    };
+    auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) z[i] = S[pj * PS + kx * 8 + i];
-        fft8<false>(z);
-#pragma unroll
-        for (int ky = 0; ky < 8; ++ky)
-            z[ky] = cmul(make_float2(rd1(z[ky].x), rd1(z[ky].y)), filt[ky * 5 + kx]);     // :461-468
-        fft8<true>(z);
-        constexpr float sc = 1.0f / 64.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) S[pj * PS + kx * 8 + i] = make_float2(z[i].x * sc, z[i].y * sc);
-    }
+        for (int i = 0; i < HPT2; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / (TW + 4), cc = idx - r * (TW + 4);
+            if (idx < HALO2) tin[r * LS2 + cc] = pre[i];
+        }
+    };
+    fetch(cbase);
+    stash();
     __syncthreads();
 
-    {
-        const int gy = ty0 + py * 8 + rr, gx = tx0 + px * 8;
+    for (int ci = 0; ci < CPB; ++ci) {
+        const int c = cbase + ci;
+        if (c >= Hd) break;                                   // uniform
+        const bool more = ci + 1 < CPB && c + 1 < Hd;
+        if (more) fetch(c + 1);                               // next channel's halo flies during this one's math
+        if (tid < 40) {
+            float sn, cs;
+            sincosf(fftp[c * 40 + tid], &sn, &cs);
+            const float a = ffta[c * 40 + tid];
+            filt[tid] = make_float2(a * cs, -a * sn);
+        }
+        float k0[9], k2[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            k0[i] = w0[c * 9 + i];
+            k2[i] = w2[c * 9 + i];
+        }
+
+        // ---- A: first depthwise conv + GELU on the (TH+2) x (TW+2) ring (zero outside the image = the
+        // zero padding the second conv sees, FDN_arch.py:439); row segments of 8 share a 3 x 10 window
+        auto ring_segment = [&](int job) {
+            const int r = job % (TH + 2), c0 = (job / (TH + 2)) * 8;   // consecutive lanes -> consecutive rows
+            float o8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float v[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v[j] = tin[(r + dy) * LS2 + c0 + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) o8[j] = fmaf(k0[dy * 3 + dx], v[j + dx], o8[j]);
+            }
+            const int y = ty0 - 1 + r;
+            const bool yok = y >= 0 && y < H;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int xx = tx0 - 1 + c0 + j;
+                mid[r * LSM + c0 + j] = (yok && xx >= 0 && xx < W) ? gelu_fast(o8[j]) : 0.f;
+            }
+        };
+        ring_segment(tid);                                        // 256 of the 272 segments
+        if (tid < 16) ring_segment(256 + tid);
+        else if (tid < 16 + 2 * (TH + 2)) {                       // columns 64, 65 of every ring row
+            const int i = tid - 16, r = i >> 1, cc = 64 + (i & 1);
+            const int y = ty0 - 1 + r, xx = tx0 - 1 + cc;
+            float a = 0.f;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) a = fmaf(k0[dy * 3 + dx], tin[(r + dy) * LS2 + cc + dx], a);
+                a = gelu_fast(a);
+            }
+            mid[r * LSM + cc] = a;
+        }
+        // forward rows of the frequency branch straight from the input tile (centre of tin)
+        {
+            float r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = tin[(2 + py * 8 + rr) * LS2 + 2 + px * 8 + i];
+            float2 o[5];
+            rfft8_row(r, o);
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) S[patch * PS + kx * 8 + rr] = o[kx];
+        }
+        __syncthreads();
+
+        // ---- B: tin is free: park the prefetched halo; second conv; column transforms --------------
+        if (more) stash();
+        float sp[8];
+        {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sp[j] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float v[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v[j] = mid[(py * 8 + rr + dy) * LSM + px * 8 + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) sp[j] = fmaf(k2[dy * 3 + dx], v[j + dx], sp[j]);
+            }
+        }
+        // columns: forward, z * ffta * e^{-i fftp}, inverse  (FDN_arch.py:460-469)
+        if (tid < NP * 5) {
+            const int pj = tid / 5, kx = tid - pj * 5;
+            float2 z[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = S[pj * PS + kx * 8 + i];
+            fft8<false>(z);
+#pragma unroll
+            for (int ky = 0; ky < 8; ++ky)
+                z[ky] = cmul(make_float2(rd1(z[ky].x), rd1(z[ky].y)), filt[ky * 5 + kx]);     // :461-468
+            fft8<true>(z);
+            constexpr float sc = 1.0f / 64.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) S[pj * PS + kx * 8 + i] = make_float2(z[i].x * sc, z[i].y * sc);
+        }
+        __syncthreads();
+
+        // ---- C: inverse rows + spatial branch, 32-byte segments to global --------------------------------
         if (gy < H && gx < W) {
             float2 xk[5];
 #pragma unroll
@@ -364,6 +413,7 @@ __global__ __launch_bounds__(256, 4) void fdffn_mid_kernel(const float* __restri
             *reinterpret_cast<float4*>(dst) = make_float4(r[0] + sp[0], r[1] + sp[1], r[2] + sp[2], r[3] + sp[3]);   // :470
             *reinterpret_cast<float4*>(dst + 4) = make_float4(r[4] + sp[4], r[5] + sp[5], r[6] + sp[6], r[7] + sp[7]);
         }
+        __syncthreads();                                          // S, mid, filt are rewritten by the next channel
     }
 }
 
@@ -386,7 +436,7 @@ extern "C" int fdn_fdffn_mid(const float* x, const float* w0, const float* w2, c
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0 && Hd < 65536 && B < 65536);
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
-    hipLaunchKernelGGL(fdffn_mid_kernel, dim3(tx * ty, Hd, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w0, w2,
+    hipLaunchKernelGGL(fdffn_mid_kernel, dim3(tx * ty, (Hd + CPB - 1) / CPB, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w0, w2,
                        ffta, fftp, out, Hd, H, W, tx);
     return fdn_launch_status();
 }
