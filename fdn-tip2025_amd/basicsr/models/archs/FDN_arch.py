@@ -95,10 +95,13 @@ class FDSA(nn.Module):
         e = self.expand_dim
         hidden = ops.conv1x1(x, _w(self.to_hidden.weight), ln=ln)
         o = ops.fdsa_core(hidden, _w(self.to_hidden_dw.weight), _w(self.fft))
-        stats = ops.chan_stats(o[:, :3 * e], groups=3)
         norms = (self.norm1, self.norm2, self.norm3)
         gam = self._c.get("g", [n.body.weight for n in norms], lambda: torch.cat([n.body.weight.detach() for n in norms]))
         bet = self._c.get("b", [n.body.bias for n in norms], lambda: torch.cat([n.body.bias.detach() for n in norms]))
+        y = ops.fdsa_out(o, _w(self.project_out.weight), gam, bet, res=res, want_stats=res is not None)   # levels 1, 2
+        if y is not None:
+            return y
+        stats = ops.chan_stats(o[:, :3 * e], groups=3)
         return ops.conv1x1(o[:, :3 * e], _w(self.project_out.weight), ln3_gate=(stats, gam, bet, o[:, 3 * e:]), res=res,
                            want_stats=res is not None)
 

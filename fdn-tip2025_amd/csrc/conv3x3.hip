@@ -41,8 +41,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(C3Args a) {
     constexpr int CH = KC * WS;
     constexpr int WPT = (KC * MT * 32) / NT;
     const int Cin = a.Cin, N = a.Cout, W = a.W, H = a.H;
+    const int Ce = (Cin + 1) & ~1;             // even channel count of the k' = tap*Ce + ci decomposition (pad channel = 0)
     const unsigned P = (unsigned)H * W, P4 = P * 4u;
-    const int Kt = 9 * Cin;
+    const int Kt = 9 * Ce;
     const int nch = (Kt + KC - 1) / KC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
     const int npass = (N + MT * 32 - 1) / (MT * 32);
@@ -52,11 +53,11 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(C3Args a) {
         float wr[WPT];
         auto w_fetch = [&](int c) {
             const int kp = c * KC + (tid & 31);
-            const int tap = kp / Cin, ci = kp - tap * Cin;
+            const int tap = kp / Ce, ci = kp - tap * Ce;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 const int n = nbase + (tid >> 5) + (NT / 32) * i;
-                wr[i] = (n < N && kp < Kt) ? a.w[((long)n * Cin + ci) * 9 + tap] : 0.f;
+                wr[i] = (n < N && kp < Kt && ci < Cin) ? a.w[((long)n * Cin + ci) * 9 + tap] : 0.f;
             }
         };
         auto w_stash = [&](int buf) {
@@ -87,16 +88,16 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(C3Args a) {
             const rsrc_t rx = mk_rsrc(a.x + (long)t.b * Cin * P, (unsigned)Cin * P4);
             const unsigned vbase = (kh * P + t.pix) * 4u;
             int k0 = c_ * KC;
-            int tap = k0 / Cin, ci = k0 - tap * Cin;           // wave-uniform
+            int tap = k0 / Ce, ci = k0 - tap * Ce;             // wave-uniform
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
                 const bool bad = tap >= 9 || (dy < 0 && t.top) || (dy > 0 && t.bot) || (dx < 0 && t.lft) || (dx > 0 && t.rgt);
                 const unsigned voff = vbase + (unsigned)((dy * W + dx) * 4);
                 const float v = bload(rx, voff, (unsigned)ci * P4);
-                xv[s] = bad ? 0.f : v;
+                xv[s] = (bad || ci + kh >= Cin) ? 0.f : v;        // pad channel / edge taps contribute nothing
                 ci += 2;
-                if (ci >= Cin) { ci -= Cin; ++tap; }
+                if (ci >= Ce) { ci -= Ce; ++tap; }
             }
         };
 
@@ -187,7 +188,7 @@ int launch(C3Args a, hipStream_t s) {
 // returns FDN_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the direct kernel)
 int fdn_conv3x3_mfma(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int Cin, int H,
                      int W, int Cout, int act, int res_before_act, float post_add, hipStream_t s) {
-    if (Cin < 8 || (Cin & 1) || Cout < 8) return FDN_ERR_UNSUPPORTED;
+    if (Cin < 2 || Cout < 8) return FDN_ERR_UNSUPPORTED;   // tiny Cout: the direct kernel wastes less
     const unsigned long long P4 = 4ull * H * W;
     if ((unsigned long long)(Cin + 2) * P4 > 0xFFFFFFFFull || (unsigned long long)(Cout + 200) * P4 > 0xFFFFFFFFull)
         return FDN_ERR_UNSUPPORTED;

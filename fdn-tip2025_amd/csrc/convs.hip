@@ -82,15 +82,22 @@ __global__ __launch_bounds__(256) void convT_kernel(const float* __restrict__ x,
 #pragma unroll
     for (int o = 0; o < OCB; ++o) acc[o] = 0.f;
     const long hw = (long)H * W;
+    // stride 2, pad 1, k 4: output row oy takes input rows iy with 2*iy = oy + 1 - ky, i.e. the two
+    // taps ky = (oy+1)&1 and ky + 2 (same for columns): 4 of the 16 taps are live per output pixel
+    const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
     for (int ci = 0; ci < Cin; ++ci) {
         const float* xc = x + ((long)b * Cin + ci) * hw;
-        for (int ky = 0; ky < 4; ++ky) {
-            const int ty = oy + 1 - ky;                 // = 2*iy
-            const bool yok = ty >= 0 && (ty & 1) == 0 && (ty >> 1) < H;
-            for (int kx = 0; kx < 4; ++kx) {
-                const int tx = ox + 1 - kx;
-                const bool ok = live && yok && tx >= 0 && (tx & 1) == 0 && (tx >> 1) < W;
-                const float v = ok ? xc[(long)(ty >> 1) * W + (tx >> 1)] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ky = ky0 + 2 * a;
+            const int iy = (oy + 1 - ky) >> 1;
+            const bool yok = (oy + 1 - ky) >= 0 && iy < H;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int kx = kx0 + 2 * c2;
+                const int ix = (ox + 1 - kx) >> 1;
+                const bool ok = live && yok && (ox + 1 - kx) >= 0 && ix < W;
+                const float v = ok ? xc[(long)iy * W + ix] : 0.f;
                 const float* wp = w + ((long)ci * Cout + oc0) * 16 + ky * 4 + kx;
 #pragma unroll
                 for (int o = 0; o < OCB; ++o)

@@ -1,0 +1,216 @@
+// FDSA tail in one launch (FDN_arch.py:633-639 + the residual of :671): three channel LayerNorms of
+// out1|out2|out3, the v_value gate, project_out (1x1, 3E -> C) and `x + ...`, plus the LayerNorm
+// statistics of the result for the next sub-block.
+//
+// A wave owns 32 pixels.  It loads ALL 3E+E inputs of its pixels exactly once into registers
+// (lane half kh holds the channels e = 2s + kh), derives the three (mean, rstd) pairs from those
+// registers (two-pass, like the reference), normalises/gates in place and feeds the values straight to
+// v_mfma_f32_32x32x2_f32 as the B operand; the transposed weights sit in LDS.  No statistics kernel,
+// no second read of the 3E-channel tensor.  Register budget limits this form to E <= 38 (level 1,
+// where this tail costs the most); levels 2 and 3 use fdn_chan_stats + fdn_conv1x1(PRO_LN3_GATE).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t mk_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+struct FoArgs {
+    const float* o;        // [B][4E][P]: out1 | out2 | out3 | v_value
+    const float* w;        // [N][3E]
+    const float* gamma;    // [3E]
+    const float* beta;     // [3E]
+    const float* res;      // [B][N][P]
+    float* out;            // [B][N][P]
+    float* stats_out;      // [B][2][P] or null
+    int B, E, N, P;
+    int tiles_per_img, total_tiles;
+};
+
+constexpr int NW = 4;
+
+// SH = ceil(E/2) k-steps per group, MT = ceil(N/32)
+template <int SH, int MT>
+__global__ __launch_bounds__(NW * 64, 2) void fdsa_out_kernel(FoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int E2 = 2 * SH;
+    constexpr int WS = MT * 32 + 1;
+    float* tg = smem;                      // gamma [3][E2]
+    float* tb = smem + 3 * E2;             // beta  [3][E2]
+    float* Wl = smem + 6 * E2;             // [3][E2][WS]
+    const int E = a.E, N = a.N;
+    const unsigned P = (unsigned)a.P, P4 = P * 4u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+
+    for (int i = tid; i < 3 * E2; i += NW * 64) {
+        const int g = i / E2, e = i - g * E2;
+        tg[i] = e < E ? a.gamma[g * E + e] : 0.f;
+        tb[i] = e < E ? a.beta[g * E + e] : 0.f;
+    }
+    for (int idx = tid; idx < 3 * E2 * MT * 32; idx += NW * 64) {
+        const int k = idx % (3 * E2), n = idx / (3 * E2);
+        const int g = k / E2, e = k - g * E2;
+        Wl[k * WS + n] = (n < N && e < E) ? a.w[(long)n * 3 * E + g * E + e] : 0.f;
+    }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int b = tile / a.tiles_per_img;
+        const unsigned p_ = (unsigned)(tile - b * a.tiles_per_img) * (NW * 32) + wave * 32 + ln;
+        const bool ok = p_ < P;
+        const unsigned pix = ok ? p_ : P - 1;
+        const float* ob = a.o + (long)b * 4 * E * P;
+        const rsrc_t r0 = mk_rsrc(ob, (unsigned)E * P4);
+        const rsrc_t r1 = mk_rsrc(ob + (long)E * P, (unsigned)E * P4);
+        const rsrc_t r2 = mk_rsrc(ob + (long)2 * E * P, (unsigned)E * P4);
+        const rsrc_t rv = mk_rsrc(ob + (long)3 * E * P, (unsigned)E * P4);
+        const unsigned voff = (kh * P + pix) * 4u;
+
+        float v0[SH], v1[SH], v2[SH], vv[SH];
+#pragma unroll
+        for (int s = 0; s < SH; ++s) {                    // channel e = 2s + kh; e >= E reads 0 (outside the descriptor)
+            const unsigned so = (unsigned)(2 * s) * P4;
+            v0[s] = bload(r0, voff, so);
+            v1[s] = bload(r1, voff, so);
+            v2[s] = bload(r2, voff, so);
+            vv[s] = bload(rv, voff, so);
+        }
+        // ---- three LayerNorm statistics from registers (two-pass; lanes l and l^32 split the channels) ----
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < SH; ++s) { m0 += v0[s]; m1 += v1[s]; m2 += v2[s]; }
+        const float invE = 1.0f / (float)E;
+        m0 = (m0 + __shfl_xor(m0, 32)) * invE;
+        m1 = (m1 + __shfl_xor(m1, 32)) * invE;
+        m2 = (m2 + __shfl_xor(m2, 32)) * invE;
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < SH; ++s) {
+            const bool live = 2 * s + kh < E;
+            const float d0 = v0[s] - m0, d1 = v1[s] - m1, d2 = v2[s] - m2;
+            q0 += live ? d0 * d0 : 0.f;
+            q1 += live ? d1 * d1 : 0.f;
+            q2 += live ? d2 * d2 : 0.f;
+        }
+        const float s0 = 1.0f / sqrtf((q0 + __shfl_xor(q0, 32)) * invE + 1e-5f);
+        const float s1 = 1.0f / sqrtf((q1 + __shfl_xor(q1, 32)) * invE + 1e-5f);
+        const float s2 = 1.0f / sqrtf((q2 + __shfl_xor(q2, 32)) * invE + 1e-5f);
+        // ---- normalise, gate (in place) --------------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < SH; ++s) {
+            const int e = 2 * s + kh;
+            v0[s] = ((v0[s] - m0) * s0 * tg[e] + tb[e]) * vv[s];                       // norm1(out1) * v_value  :633,636
+            v1[s] = ((v1[s] - m1) * s1 * tg[E2 + e] + tb[E2 + e]) * vv[s];             // :634,637
+            v2[s] = ((v2[s] - m2) * s2 * tg[2 * E2 + e] + tb[2 * E2 + e]) * vv[s];     // :635,638
+        }
+        // ---- project_out on MFMA -----------------------------------------------------------------------------
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < SH; ++s) {
+            const float* w0 = Wl + (2 * s + kh) * WS + ln;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[m * 32], v0[s], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[E2 * WS + m * 32], v1[s], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[2 * E2 * WS + m * 32], v2[s], acc[m], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: residual, store, next LayerNorm's statistics ------------------------------------------
+        if (ok) {
+            const unsigned nb4 = (unsigned)N * P4;
+            const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
+            const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
+            const unsigned vo = (4u * kh * P + pix) * 4u;
+            float sm = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                    const unsigned so = (unsigned)nrow * P4;
+                    float v = acc[m][r];
+                    if (a.res) v += bload(rr, vo, so);
+                    bstore(v, ro, vo, so);
+                    v = (nrow + 4 * kh < N) ? v : 0.f;
+                    acc[m][r] = v;
+                    sm += v;
+                }
+            if (a.stats_out) {
+                sm += __shfl_xor(sm, 32);
+                const float mean = sm / (float)N;
+                float sq = 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        const float dlt = acc[m][r] - mean;
+                        sq += (n < N) ? dlt * dlt : 0.f;
+                    }
+                sq += __shfl_xor(sq, 32);
+                if (kh == 0) {
+                    float* sp = a.stats_out + (long)b * 2 * P;
+                    sp[pix] = mean;
+                    sp[P + pix] = 1.0f / sqrtf(sq / (float)N + 1e-5f);
+                }
+            }
+        }
+    }
+}
+
+int g_cus = 0;
+
+template <int SH, int MT>
+int launch(FoArgs a, hipStream_t s) {
+    const size_t lds = (6UL * 2 * SH + 3UL * 2 * SH * (MT * 32 + 1)) * sizeof(float);
+    if (g_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
+        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    a.tiles_per_img = cdiv(a.P, NW * 32);
+    a.total_tiles = a.B * a.tiles_per_img;
+    auto kern = fdsa_out_kernel<SH, MT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return FDN_ERR_LAUNCH;
+    int per_cu = (int)((160 * 1024) / lds);
+    const int want = 2;
+    if (per_cu > want) per_cu = want;
+    if (per_cu < 1) per_cu = 1;
+    int grid = g_cus * per_cu;
+    if (grid > a.total_tiles) grid = a.total_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
+    return fdn_launch_status();
+}
+
+}  // namespace
+
+extern "C" int fdn_fdsa_out(const float* o, const float* w, const float* gamma3, const float* beta3, const float* res,
+                            float* out, float* stats_out, int B, int E, int N, int P, fdn_stream_t stream) {
+    FDN_CHECK_ARG(o && w && gamma3 && beta3 && out && B > 0 && E > 0 && N > 0 && P > 0);
+    if ((unsigned long long)(4 * E + 2) * 4ull * P > 0xFFFFFFFFull || (unsigned long long)(N + 40) * 4ull * P > 0xFFFFFFFFull)
+        return FDN_ERR_UNSUPPORTED;
+    FoArgs a;
+    a.o = o; a.w = w; a.gamma = gamma3; a.beta = beta3; a.res = res; a.out = out; a.stats_out = stats_out;
+    a.B = B; a.E = E; a.N = N; a.P = P;
+    a.tiles_per_img = a.total_tiles = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int sh = (E + 1) / 2, mt = (N + 31) / 32;
+    if (sh <= 19 && mt == 1) return launch<19, 1>(a, s);       // level 1: E = 38, C = 32
+    return FDN_ERR_UNSUPPORTED;                                  // caller falls back to stats + conv1x1
+}

@@ -47,17 +47,16 @@ __device__ __forceinline__ void bstore(float v, rsrc_t r, unsigned voff, unsigne
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
-template <int MT, int PRO, int NW, int KS>
-__global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ? 3 : 2))) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
+template <int MT, int PRO, int NW>
+__global__ __launch_bounds__(NW * 64) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = NW * 64;
-    constexpr int KCH = 2 * KS;                // K chunk: KS MFMA k-steps
     constexpr int WS = MT * 32 + 1;            // LDS row stride of the transposed weight chunk
-    constexpr int CH = KCH * WS;               // floats per chunk buffer
+    constexpr int CH = KC * WS;                // floats per chunk buffer
     const int K = d.K, N = d.N;
     const unsigned P = (unsigned)d.P, P4 = P * 4u;
-    const int nch = (K + KCH - 1) / KCH;
-    const int Kp = nch * KCH;
+    const int nch = (K + KC - 1) / KC;
+    const int Kp = nch * KC;
     float* tg = smem;                          // gamma[Kp]
     float* tb = smem + Kp;                     // beta[Kp]
     float* Wl = smem + 2 * Kp;                 // weight chunks
@@ -74,7 +73,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
     const int E = d.ln_group;
     const int ks0 = d.kseg[0], ks01 = d.kseg[0] + d.kseg[1];
     const int npass = (N + MT * 32 - 1) / (MT * 32);
-    constexpr int WPT = (KCH * MT * 32) / NT;   // weight elements per thread per chunk
+    constexpr int WPT = (KC * MT * 32) / NT;   // weight elements per thread per chunk
 
     for (int pass = 0; pass < npass; ++pass) {
         const int nbase = pass * MT * 32;
@@ -82,18 +81,18 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
         // ---- weight chunk loader: W[n][k] (lanes along k) -> regs -> Wl[buf][k][n] ---------------
         float wr[WPT];
         auto w_fetch = [&](int c) {
-            const int kk = tid % KCH, k = c * KCH + kk;
+            const int kk = tid & 31, k = c * KC + kk;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
-                const int n = nbase + tid / KCH + (NT / KCH) * i;
+                const int n = nbase + (tid >> 5) + (NT / 32) * i;
                 wr[i] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
             }
         };
         auto w_stash = [&](int buf) {
-            const int kk = tid % KCH;
+            const int kk = tid & 31;
             float* dst = Wl + buf * CH + kk * WS;
 #pragma unroll
-            for (int i = 0; i < WPT; ++i) dst[tid / KCH + (NT / KCH) * i] = wr[i];
+            for (int i = 0; i < WPT; ++i) dst[(tid >> 5) + (NT / 32) * i] = wr[i];
         };
         __syncthreads();                       // previous pass finished reading Wl; tables written
         if (g.resident) {
@@ -108,8 +107,8 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
         int tile = blockIdx.x, c = 0;
         bool live = tile < g.total_tiles;
 
-        float xa[KS], xb[KS];                  // current (prologue applied) / prefetched activations
-        float yb[KS];                          // prefetched second operand (v_value / x1) for PRO 2,3
+        float xa[16], xb[16];                  // current / prefetched activations
+        float ya[16], yb[16];                  // second operand (v_value / x1) for PRO 2,3
         float mu[3], rs[3];                    // LayerNorm statistics of this lane's pixel
 
         struct Tile { int b; unsigned pix; bool ok; };
@@ -121,14 +120,14 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
             r.pix = r.ok ? p_ : P - 1;         // clamp: harmless loads, never stored
             return r;
         };
-        auto x_issue = [&](const Tile& t, int c_, float (&xv)[KS], float (&yv)[KS]) {
+        auto x_issue = [&](const Tile& t, int c_, float (&xv)[16], float (&yv)[16]) {
             const rsrc_t r0 = mk_rsrc(d.x[0] + (long)t.b * d.xbs[0], (unsigned)ks0 * P4);
             const rsrc_t r1 = mk_rsrc(d.x[1] + (long)t.b * d.xbs[1], (unsigned)d.kseg[1] * P4);
             const rsrc_t r2 = mk_rsrc(d.x[2] + (long)t.b * d.xbs[2], (unsigned)d.kseg[2] * P4);
             const unsigned voff = (kh * P + t.pix) * 4u;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int k = c_ * KCH + 2 * s;                     // wave-uniform, even
+            for (int s = 0; s < 16; ++s) {
+                const int k = c_ * KC + 2 * s;                      // wave-uniform, even
                 if (k < ks0) xv[s] = bload(r0, voff, (unsigned)k * P4);
                 else if (k < ks01) xv[s] = bload(r1, voff, (unsigned)(k - ks0) * P4);
                 else xv[s] = bload(r2, voff, (unsigned)(k - ks01) * P4);
@@ -136,15 +135,15 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
             if (PRO == FDN_PRO_LN3_GATE) {
                 const rsrc_t ry = mk_rsrc(d.xb + (long)t.b * d.xbbs, (unsigned)E * P4);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int k = c_ * KCH + 2 * s + kh;
+                for (int s = 0; s < 16; ++s) {
+                    const int k = c_ * KC + 2 * s + kh;
                     const int e = k - ((k >= E) + (k >= 2 * E)) * E;
                     yv[s] = bload(ry, ((unsigned)e * P + t.pix) * 4u, 0u);
                 }
             } else if (PRO == FDN_PRO_LN_MULADD) {
                 const rsrc_t ry = mk_rsrc(d.xb + (long)t.b * d.xbbs, (unsigned)K * P4);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) yv[s] = bload(ry, voff, (unsigned)(c_ * KCH + 2 * s) * P4);
+                for (int s = 0; s < 16; ++s) yv[s] = bload(ry, voff, (unsigned)(c_ * KC + 2 * s) * P4);
             }
         };
         auto stats_load = [&](const Tile& t) {
@@ -166,33 +165,10 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-        // adopt the prefetched chunk: apply the prologue once, into xa
-        auto adopt = [&](int c_) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                float bv = xb[s];
-                if (PRO != FDN_PRO_NONE) {
-                    const int k = c_ * KCH + 2 * s + kh;
-                    const float ga = tg[k], be = tb[k];
-                    if (PRO == FDN_PRO_LN) {
-                        bv = (bv - mu[0]) * rs[0] * ga + be;
-                    } else if (PRO == FDN_PRO_LN3_GATE) {
-                        const int q = (k >= E) + (k >= 2 * E);
-                        const float m_ = q == 0 ? mu[0] : (q == 1 ? mu[1] : mu[2]);
-                        const float r_ = q == 0 ? rs[0] : (q == 1 ? rs[1] : rs[2]);
-                        bv = ((bv - m_) * r_ * ga + be) * yb[s];
-                    } else {
-                        bv = ((bv - mu[0]) * rs[0] * ga + be) * yb[s] + yb[s];
-                    }
-                }
-                xa[s] = bv;
-            }
-        };
         Tile cur = tile_setup(live ? tile : 0);
         if (live) {
             stats_load(cur);
-            x_issue(cur, 0, xb, yb);
-            adopt(0);
+            x_issue(cur, 0, xa, ya);
         }
         int step = 0;
         while (live) {
@@ -210,11 +186,26 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
             // ---- compute step (tile, c) -----------------------------------------------------------
             const float* Wc = Wl + (g.resident ? c : (step & 1)) * CH;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int s = 0; s < 16; ++s) {
+                float bv = xa[s];
+                if (PRO != FDN_PRO_NONE) {
+                    const int k = c * KC + 2 * s + kh;
+                    const float ga = tg[k], be = tb[k];
+                    if (PRO == FDN_PRO_LN) {
+                        bv = (bv - mu[0]) * rs[0] * ga + be;
+                    } else if (PRO == FDN_PRO_LN3_GATE) {
+                        const int q = (k >= E) + (k >= 2 * E);
+                        const float m_ = q == 0 ? mu[0] : (q == 1 ? mu[1] : mu[2]);
+                        const float r_ = q == 0 ? rs[0] : (q == 1 ? rs[1] : rs[2]);
+                        bv = ((bv - m_) * r_ * ga + be) * ya[s];
+                    } else {
+                        bv = ((bv - mu[0]) * rs[0] * ga + be) * ya[s] + ya[s];
+                    }
+                }
                 const float* wrow = Wc + (2 * s + kh) * WS + ln;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[m * 32], xa[s], acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[m * 32], bv, acc[m], 0, 0, 0);
             }
 
             // ---- epilogue at the last chunk of a tile --------------------------------------------------
@@ -279,7 +270,8 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
             }
             // advance
             if (nlive && nc == 0) { cur = nxt; stats_load(cur); }
-            if (nlive) adopt(nc);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { xa[s] = xb[s]; ya[s] = yb[s]; }
             tile = ntile; c = nc; live = nlive;
             ++step;
         }
@@ -295,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ?
 // after the weights are loaded.  Used for to_hidden / project_in (K = C) where N is 2.7-4.8 x K.
 // ------------------------------------------------------------------------------------------------
 template <int NCH, int PRO, int NW>
-__global__ __launch_bounds__(NW * 64, (NCH == 1 ? 4 : 3)) void conv1x1_smallk_kernel(fdn_conv1x1_desc d, Geo g) {
+__global__ __launch_bounds__(NW * 64) void conv1x1_smallk_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = NW * 64;
     constexpr int Kp = NCH * KC;
@@ -424,17 +416,15 @@ int g_num_cu = 0;
 
 template <int MT, int PRO, int NW>
 int launch(const fdn_conv1x1_desc& d, hipStream_t s) {
-    constexpr int KS = 16;
-    constexpr int KCH = 2 * KS;
-    const int nch = (d.K + KCH - 1) / KCH;
-    const size_t tab = 2UL * nch * KCH * sizeof(float);
-    const size_t chunk = (size_t)KCH * (MT * 32 + 1) * sizeof(float);
+    const int nch = (d.K + KC - 1) / KC;
+    const size_t tab = 2UL * nch * KC * sizeof(float);
+    const size_t chunk = (size_t)KC * (MT * 32 + 1) * sizeof(float);
     Geo g;
     g.resident = (tab + nch * chunk <= 96 * 1024) ? 1 : 0;
     const size_t lds = tab + (g.resident ? nch : 2) * chunk;
     g.tiles_per_img = cdiv(d.P, NW * 32);
     g.total_tiles = d.B * g.tiles_per_img;
-    auto kern = conv1x1_kernel<MT, PRO, NW, KS>;
+    auto kern = conv1x1_kernel<MT, PRO, NW>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
@@ -448,9 +438,7 @@ int launch(const fdn_conv1x1_desc& d, hipStream_t s) {
     }
     // persistent grid: as many workgroups as can be co-resident (LDS / register limited), capped by the work
     int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
-    const int want = (MT == 1 ? (PRO >= 2 ? 3 : 4) : (MT == 2 ? 3 : 2)) * 4 / NW;   // register-limited waves per SIMD -> workgroups per CU
-    if (per_cu > want) per_cu = want;
-    if (NW == 8 && per_cu > 2) per_cu = 2;
+    if (per_cu > 2) per_cu = 2;                                 // 8-wave workgroups: 2 per CU = 4 waves per SIMD
     if (per_cu < 1) per_cu = 1;
     int grid = g_num_cu * per_cu;
     if (grid > g.total_tiles) grid = g.total_tiles;
@@ -504,24 +492,13 @@ int launch_smallk_nch(const fdn_conv1x1_desc& d, hipStream_t s) {
     return launch_smallk<2, PRO>(d, s);
 }
 
-template <int MT, int PRO>
-int launch_nw(const fdn_conv1x1_desc& d, hipStream_t s) {
-    // LDS-limited to one workgroup per CU (big resident weight slice) -> give that workgroup 8 waves
-    const int nch = (d.K + KC - 1) / KC;
-    const size_t slice = 2UL * nch * KC * 4 + (size_t)nch * KC * (MT * 32 + 1) * 4;
-    const bool one_per_cu = slice > 80 * 1024 && slice <= 96 * 1024;
-    const bool streaming = slice > 96 * 1024;
-    if (one_per_cu || streaming) return launch<MT, PRO, 8>(d, s);
-    return launch<MT, PRO, 4>(d, s);
-}
-
 template <int MT>
 int launch_pro(const fdn_conv1x1_desc& d, hipStream_t s) {
     switch (d.pro) {
-        case FDN_PRO_NONE: return launch_nw<MT, FDN_PRO_NONE>(d, s);
-        case FDN_PRO_LN: return launch_nw<MT, FDN_PRO_LN>(d, s);
-        case FDN_PRO_LN3_GATE: return launch_nw<MT, FDN_PRO_LN3_GATE>(d, s);
-        case FDN_PRO_LN_MULADD: return launch_nw<MT, FDN_PRO_LN_MULADD>(d, s);
+        case FDN_PRO_NONE: return launch<MT, FDN_PRO_NONE, 8>(d, s);
+        case FDN_PRO_LN: return launch<MT, FDN_PRO_LN, 8>(d, s);
+        case FDN_PRO_LN3_GATE: return launch<MT, FDN_PRO_LN3_GATE, 8>(d, s);
+        case FDN_PRO_LN_MULADD: return launch<MT, FDN_PRO_LN_MULADD, 8>(d, s);
         default: return FDN_ERR_ARG;
     }
 }

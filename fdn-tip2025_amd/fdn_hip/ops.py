@@ -126,6 +126,24 @@ def fdsa_core(hidden, dw_w, fft_w):
     return out
 
 
+def fdsa_out(o, w, gamma3, beta3, res=None, want_stats=False):
+    """Fused FDSA tail (fdn_fdsa_out).  Returns None when the size is not covered (E > 76 or N > 64)."""
+    B, C4, H, W = o.shape
+    E, N, P = C4 // 4, w.shape[0], H * W
+    if E > 38 or N > 32:          # register-resident form: level 1 (and the dim-24 variant's level 1)
+        return None
+    out = torch.empty((B, N, H, W), device=o.device, dtype=torch.float32)
+    stats = torch.empty((B, 1, 2, P), device=o.device, dtype=torch.float32) if want_stats else None
+    rc = lib().fdn_fdsa_out(_flat(o, "o"), _flat(w, "w"), _flat(gamma3, "gamma3"), _flat(beta3, "beta3"), _flat(res, "res"),
+                            _flat(out, "out"), _flat(stats, "stats_out"), B, E, N, P, stream())
+    if rc == 4:          # FDN_ERR_UNSUPPORTED
+        return None
+    check(rc, "fdn_fdsa_out")
+    if want_stats:
+        out._fdn_stats = stats
+    return out
+
+
 def fdffn_mid(x, w0, w2, ffta, fftp):
     B, Hd, H, W = x.shape
     out = torch.empty_like(x)

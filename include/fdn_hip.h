@@ -89,6 +89,14 @@ int fdn_layernorm_chan(const float* x, const float* gamma, const float* beta, fl
 int fdn_fdsa_core(const float* hidden, const float* dw_w, const float* fft_w, float* out, int B, int E, int H, int W,
                   fdn_stream_t stream);
 
+/* FDSA tail in one launch (FDN_arch.py:633-639 and the residual add of :671): norm1/2/3 over the E channels
+ * of out1|out2|out3, times v_value, project_out (3E -> N) + res, and (optionally) the channel LayerNorm
+ * statistics of the result.  o [B][4E][P] as written by fdn_fdsa_core; w [N][3E]; gamma3,beta3 [3E];
+ * stats_out [B][2][P] or NULL.  Register-resident form, E <= 76 and N <= 64: other sizes return
+ * FDN_ERR_UNSUPPORTED (use fdn_chan_stats + fdn_conv1x1 with FDN_PRO_LN3_GATE). */
+int fdn_fdsa_out(const float* o, const float* w, const float* gamma3, const float* beta3, const float* res, float* out,
+                 float* stats_out, int B, int E, int N, int P, fdn_stream_t stream);
+
 /* FDFFN middle: spatial branch dw3x3 -> GELU -> dw3x3 (FDN_arch.py:435-441,457) plus frequency
  * branch 8x8 rfft2 -> replace_denormals -> amplitude*ffta, phase-fftp -> irfft2 (:458-469), summed
  * (:470).  x [B][Hd][H][W], w0,w2 [Hd][9], ffta,fftp [Hd][8][5] -> out [B][Hd][H][W]. */
