@@ -278,6 +278,32 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_kernel(fdn_conv1x1_desc d, Ge
     }
 }
 
+// One accumulator, STEPS k-steps: acc += W[k][n] * x[k] with the A operand read from LDS eight k-steps
+// ahead of its MFMA into a second register set (hipcc otherwise reuses one register pair and exposes
+// the full ds_read latency every two MFMAs).  `w` points at this lane's element of k-step 0;
+// consecutive k-steps are `stride` floats apart.
+template <int STEPS>
+__device__ __forceinline__ void mfma_chain(f32x16& acc, const float* w, int stride, const float* x) {
+    static_assert(STEPS % 8 == 0, "k-steps come in groups of 8");
+    float a[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[0][i] = w[i * stride];
+#pragma unroll
+    for (int g = 0; g < STEPS / 8; ++g) {
+        if (g + 1 < STEPS / 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[(g + 1) & 1][i] = w[((g + 1) * 8 + i) * stride];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i], x[g * 8 + i], acc, 0, 0, 0);
+            // 1 MFMA then (while it runs) 1 LDS read of the next group: keep the two streams interleaved
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small-K variant (K <= 128, whole transposed weight matrix resident in LDS): the wave keeps its
 // 32-pixel activation strip for ALL K in registers (K/2 VGPRs), applies the prologue once, and then
@@ -378,10 +404,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_kernel(fdn_conv1x1_des
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float* wcol = Wl + kh * NS + m * 32 + ln;
-#pragma unroll
-            for (int s = 0; s < NCH * 16; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[2 * s * NS], xa[s], acc, 0, 0, 0);
+            mfma_chain<NCH * 16>(acc, Wl + kh * NS + m * 32 + ln, 2 * NS, xa);
             if (cur.ok) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -395,6 +418,119 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_kernel(fdn_conv1x1_des
                     bstore(v, ro, voff, soff);
                 }
             }
+        }
+        cur = nxt; tile = ntile; live = nlive;
+    }
+}
+
+// Small-K, large-N variant whose weight matrix does NOT fit LDS (level 3: 128 -> 612 / 345): same
+// register-resident activation strip, but the 32-channel weight tiles stream through a double
+// buffer in LDS (one barrier per output tile).  The strip of the NEXT pixel tile is requested a
+// whole tile (ntiles x 64*NCH MFMA cycles) ahead, the next weight tile one step ahead, so neither
+// HBM nor L2 latency is exposed to the MFMA pipe.
+template <int NCH, int PRO, int NW>
+__global__ __launch_bounds__(NW * 64) void conv1x1_smallk_stream_kernel(fdn_conv1x1_desc d, Geo g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = NW * 64;
+    constexpr int Kp = NCH * KC;
+    constexpr int WS = 33;
+    constexpr int WPT = (Kp * 32) / NT;
+    const int K = d.K, N = d.N;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int ntiles = (N + 31) / 32;
+    float* tg = smem;
+    float* tb = smem + Kp;
+    float* Wl = smem + 2 * Kp;                 // [2][Kp][WS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+
+    for (int i = tid; i < Kp; i += NT) {
+        tg[i] = (PRO != FDN_PRO_NONE && i < K) ? d.gamma[i] : 0.f;
+        tb[i] = (PRO != FDN_PRO_NONE && i < K) ? d.beta[i] : 0.f;
+    }
+    float wr[WPT];
+    auto w_fetch = [&](int m) {
+        const int k = tid % Kp;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int n = m * 32 + tid / Kp + (NT / Kp) * i;
+            wr[i] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
+        }
+    };
+    auto w_stash = [&](int buf) {
+        float* dst = Wl + buf * (Kp * WS) + (tid % Kp) * WS;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) dst[tid / Kp + (NT / Kp) * i] = wr[i];
+    };
+    w_fetch(0);
+    w_stash(0);
+    __syncthreads();
+
+    struct Tile { int b; unsigned pix; bool ok; };
+    auto tile_setup = [&](int t) {
+        Tile r;
+        r.b = t / g.tiles_per_img;
+        const unsigned p_ = (unsigned)(t - r.b * g.tiles_per_img) * (NW * 32) + wave * 32 + ln;
+        r.ok = p_ < P;
+        r.pix = r.ok ? p_ : P - 1;
+        return r;
+    };
+    float xa[NCH * 16], xb[NCH * 16];
+    float mu_n = 0.f, rs_n = 0.f;
+    auto x_issue = [&](const Tile& t) {
+        const rsrc_t r0 = mk_rsrc(d.x[0] + (long)t.b * d.xbs[0], (unsigned)K * P4);
+        const unsigned voff = (kh * P + t.pix) * 4u;
+#pragma unroll
+        for (int s = 0; s < NCH * 16; ++s) xb[s] = bload(r0, voff, (unsigned)(2 * s) * P4);
+        if (PRO != FDN_PRO_NONE) {
+            const float* sp = d.stats + (long)t.b * 2 * P;
+            mu_n = sp[t.pix];
+            rs_n = sp[P + t.pix];
+        }
+    };
+
+    int tile = blockIdx.x;
+    bool live = tile < g.total_tiles;
+    Tile cur = tile_setup(live ? tile : 0);
+    if (live) x_issue(cur);
+    int wstep = 0;                              // running output-tile counter -> weight buffer parity
+    while (live) {
+#pragma unroll
+        for (int s = 0; s < NCH * 16; ++s) {
+            float v = xb[s];
+            if (PRO != FDN_PRO_NONE) v = (v - mu_n) * rs_n * tg[2 * s + kh] + tb[2 * s + kh];
+            xa[s] = v;
+        }
+        const int ntile = tile + gridDim.x;
+        const bool nlive = ntile < g.total_tiles;
+        const Tile nxt = tile_setup(nlive ? ntile : tile);
+        if (nlive) x_issue(nxt);
+
+        const unsigned nb4 = (unsigned)N * P4;
+        const rsrc_t ro = mk_rsrc(d.out + (long)cur.b * d.obs, nb4);
+        const rsrc_t rr = mk_rsrc(d.res ? d.res + (long)cur.b * d.rbs : d.out, d.res ? nb4 : 0u);
+        const unsigned voff = (4u * kh * P + cur.pix) * 4u;
+        for (int m = 0; m < ntiles; ++m, ++wstep) {
+            const int mnext = (m + 1 < ntiles) ? m + 1 : 0;
+            const bool more = (m + 1 < ntiles) || nlive;
+            if (more) w_fetch(mnext);                              // next weight tile: L2 -> registers
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            mfma_chain<NCH * 16>(acc, Wl + (wstep & 1) * (Kp * WS) + kh * WS + ln, 2 * WS, xa);
+            if (cur.ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                    const unsigned soff = (unsigned)nrow * P4;
+                    float v = acc[r];
+                    if (d.bias) { const int n = nrow + 4 * kh; v += (n < N) ? d.bias[n] : 0.f; }
+                    v = apply_act(v, d.act);
+                    if (d.epi == FDN_EPI_RES) v += bload(rr, voff, soff);
+                    bstore(v, ro, voff, soff);
+                }
+            }
+            if (more) w_stash((wstep + 1) & 1);
+            __syncthreads();
         }
         cur = nxt; tile = ntile; live = nlive;
     }
@@ -476,6 +612,34 @@ int launch_smallk(const fdn_conv1x1_desc& d, hipStream_t s) {
     return fdn_launch_status();
 }
 
+template <int NCH, int PRO>
+int launch_smallk_stream(const fdn_conv1x1_desc& d, hipStream_t s) {
+    constexpr int NW = 8;
+    const size_t lds = (2UL * NCH * KC + 2UL * NCH * KC * 33) * sizeof(float);
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    Geo g;
+    g.resident = 0;
+    g.tiles_per_img = cdiv(d.P, NW * 32);
+    g.total_tiles = d.B * g.tiles_per_img;
+    int grid = g_num_cu;                                           // 8 waves x ~190 VGPRs: one workgroup per CU
+    if (grid > g.total_tiles) grid = g.total_tiles;
+    hipLaunchKernelGGL((conv1x1_smallk_stream_kernel<NCH, PRO, NW>), dim3(grid), dim3(NW * 64), lds, s, d, g);
+    return fdn_launch_status();
+}
+
+// K <= 128, N >= 2K, single input segment, plain/LN prologue, no muladd epilogue, weights too big for LDS
+bool smallk_stream_ok(const fdn_conv1x1_desc& d) {
+    if (d.K > 128 || d.K <= 64 || d.stats_out || d.kseg[1] > 0) return false;
+    if (d.pro != FDN_PRO_NONE && d.pro != FDN_PRO_LN) return false;
+    if (d.epi == FDN_EPI_MULADD) return false;
+    return d.N >= 2 * d.K;
+}
+
 // true when the small-K kernel covers this problem
 bool smallk_ok(const fdn_conv1x1_desc& d) {
     if (d.K > 64 || d.stats_out || d.pro == FDN_PRO_LN3_GATE) return false;
@@ -527,6 +691,11 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         if (d.kseg[1] > 0 && ((d.kseg[0] & 1) || (d.kseg[1] & 1))) return FDN_ERR_UNSUPPORTED;   // k-step pairs must not straddle segments
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (smallk_stream_ok(d)) {
+        const int nch = (d.K + KC - 1) / KC;
+        if (d.pro == FDN_PRO_LN) return nch == 3 ? launch_smallk_stream<3, FDN_PRO_LN>(d, s) : launch_smallk_stream<4, FDN_PRO_LN>(d, s);
+        return nch == 3 ? launch_smallk_stream<3, FDN_PRO_NONE>(d, s) : launch_smallk_stream<4, FDN_PRO_NONE>(d, s);
+    }
     if (smallk_ok(d)) {
         switch (d.pro) {
             case FDN_PRO_NONE: return launch_smallk_nch<FDN_PRO_NONE>(d, s);
