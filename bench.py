@@ -65,7 +65,7 @@ class KernelTimer:
         import fdn_hip
         self.lib = fdn_hip.lib()
         self.records = []
-        self.names = [n for n in ("fdn_conv1x1", "fdn_fdsa_out", "fdn_chan_stats", "fdn_layernorm_chan", "fdn_fdsa_core", "fdn_fdffn_mid",
+        self.names = [n for n in ("fdn_conv1x1", "fdn_fdsa_out", "fdn_ffn_tail", "fdn_chan_stats", "fdn_layernorm_chan", "fdn_fdsa_core", "fdn_fdffn_mid",
                                   "fdn_dwconv_gate", "fdn_dwconv3x3", "fdn_img_mod_maps", "fdn_rfft_rows", "fdn_irfft_rows",
                                   "fdn_fft_cols_fcaffn", "fdn_fft_cols_fwd", "fdn_fft_cols_inv_polar", "fdn_conv2d",
                                   "fdn_conv_transpose4x4s2", "fdn_resample", "fdn_dw1x1_pad1", "fdn_avgpool3s2",

@@ -111,7 +111,7 @@ class FDSA(nn.Module):
 
 class FDFFN(nn.Module):
     """Frequency-domain FFN (reference FDN_arch.py:430-475).
-    HIP path: GEMM (project_in) -> fdn_fdffn_mid -> fdn_dwconv_gate -> GEMM (project_out + residual)."""
+    HIP path: GEMM (project_in) -> fdn_fdffn_mid -> fdn_ffn_tail (gate + project_out + residual in one launch)."""
 
     def __init__(self, dim, bias=False, r=2.7, use_light=True, use_img=True):
         super().__init__()
@@ -130,8 +130,7 @@ class FDFFN(nn.Module):
     def fused(self, x, ln=None, res=None):
         h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln)
         y = ops.fdffn_mid(h, _w(self.space[0].weight), _w(self.space[2].weight), _w(self.ffta), _w(self.fftp))
-        g = ops.dwconv_gate(y, _w(self.dwconv.weight))
-        return ops.conv1x1(g, _w(self.project_out.weight), res=res, want_stats=res is not None)
+        return ops.ffn_tail(y, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None)
 
     def forward(self, x, x_high=None, xp2=None, x_img=None):
         return self.fused(x)
@@ -167,8 +166,7 @@ class FCAFFN(nn.Module):
                                     _w(self.conv1_add.weight), _w(self.conv3_add.weight))
         gam, bet = self.norm.params()
         t = ops.conv1x1(xi, _w(self.project_in.weight), ln_muladd=(stats, gam, bet, xn), muladd=(mul, add))
-        g = ops.dwconv_gate(t, _w(self.dwconv.weight))
-        return ops.conv1x1(g, _w(self.project_out.weight), res=res, want_stats=res is not None)
+        return ops.ffn_tail(t, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None)
 
     def forward(self, x, x_high, xp2, x_img=None):
         return self.fused(x, x_high, xp2, x_img)

@@ -152,6 +152,26 @@ def fdffn_mid(x, w0, w2, ffta, fftp):
     return out
 
 
+def ffn_tail(y, dw_w, w, res=None, want_stats=False):
+    """gate + project_out + residual (+ next LayerNorm statistics) in one launch (fdn_ffn_tail)."""
+    B, C, H, W = y.shape
+    N = w.shape[0]
+    # measured on MI355X (tools/bench_kernels.py tail): the fused launch wins where the projection is wide
+    # (level 3, and level-2 FCAFFN); at level 1 the stencil VALU work per MFMA is too high and the
+    # two-launch form (gate kernel + MFMA GEMM) is ~15 % faster
+    fused = N == 128 or (N == 64 and C <= 64)
+    if not fused:
+        g = dwconv_gate(y, dw_w)
+        return conv1x1(g, w, res=res, want_stats=want_stats)
+    out = torch.empty((B, N, H, W), device=y.device, dtype=torch.float32)
+    stats = torch.empty((B, 1, 2, H * W), device=y.device, dtype=torch.float32) if want_stats else None
+    check(lib().fdn_ffn_tail(_flat(y, "y"), _flat(dw_w, "dw_w"), _flat(w, "w"), _flat(res, "res"), _flat(out, "out"),
+                             _flat(stats, "stats_out"), B, C, N, H, W, stream()), "fdn_ffn_tail")
+    if want_stats:
+        out._fdn_stats = stats
+    return out
+
+
 def dwconv_gate(x, w):
     B, C, H, W = x.shape
     out = torch.empty_like(x)

@@ -108,6 +108,12 @@ int fdn_fdffn_mid(const float* x, const float* w0, const float* w2, const float*
  * out[j] = gelu(dw(x[j/2], w[j])) * dw(x[(C+j)/2], w[C+j]). */
 int fdn_dwconv_gate(const float* x, const float* w, float* out, int B, int C, int H, int W, fdn_stream_t stream);
 
+/* FDFFN / FCAFFN tail in one launch: gated depthwise conv (FDN_arch.py:472-473, :426-427) + project_out
+ * (:474, :428) + residual (:673, :675) + LayerNorm statistics of the result.  y [B][C][H][W]; dw_w [2C][9];
+ * w [N][C]; res/out [B][N][H][W]; stats_out [B][2][H*W] or NULL.  N <= 128. */
+int fdn_ffn_tail(const float* y, const float* dw_w, const float* w, const float* res, float* out, float* stats_out, int B,
+                 int C, int N, int H, int W, fdn_stream_t stream);
+
 /* Plain depthwise 3x3 (zero pad 1), optional activation.  x,out [B][C][H][W], w [C][9]. */
 int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, int C, int H, int W, int act, fdn_stream_t stream);
 
