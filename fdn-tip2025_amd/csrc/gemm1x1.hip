@@ -448,18 +448,22 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_stream_kernel(fdn_conv
         tb[i] = (PRO != FDN_PRO_NONE && i < K) ? d.beta[i] : 0.f;
     }
     float wr[WPT];
+    // element idx = tid + NT*i of the [32 n][Kp k] weight tile (k fastest: coalesced rows of W[n][:])
     auto w_fetch = [&](int m) {
-        const int k = tid % Kp;
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int n = m * 32 + tid / Kp + (NT / Kp) * i;
+            const int idx = tid + NT * i;
+            const int k = idx % Kp, n = m * 32 + idx / Kp;
             wr[i] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
         }
     };
     auto w_stash = [&](int buf) {
-        float* dst = Wl + buf * (Kp * WS) + (tid % Kp) * WS;
+        float* dst = Wl + buf * (Kp * WS);
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) dst[tid / Kp + (NT / Kp) * i] = wr[i];
+        for (int i = 0; i < WPT; ++i) {
+            const int idx = tid + NT * i;
+            dst[(idx % Kp) * WS + idx / Kp] = wr[i];
+        }
     };
     w_fetch(0);
     w_stash(0);

@@ -191,3 +191,134 @@ def test_no_cpu_fallback(A):
     m = A.FDN().eval()
     with pytest.raises(Exception):
         m(torch.rand(1, 3, 32, 32), ratio_i=torch.rand(1, 1))
+
+
+# ---------------------------------------------------------------------------------------------------
+# entry points that only the big shapes exercise, checked directly against fp64 math
+# ---------------------------------------------------------------------------------------------------
+def _rnd(*s, seed):
+    return torch.randn(*s, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("K,N,H,W,pro", [(32, 152, 24, 40, "ln"), (64, 304, 16, 24, "ln"), (128, 612, 8, 24, "ln"),
+                                        (96, 345, 8, 16, "none"), (86, 32, 46, 21, "none"), (459, 128, 8, 16, "ln3"),
+                                        (114, 32, 24, 40, "ln3"), (32, 32, 16, 24, "muladd")])
+def test_conv1x1_variants(A, K, N, H, W, pro):
+    """Every GEMM kernel variant (small-K resident / streaming, generic resident / streaming, prologues,
+    epilogues, fused statistics) against fp64."""
+    from fdn_hip import ops
+    B = 2
+    x, w, res = _rnd(B, K, H, W, seed=1) * 1.5 + 0.3, _rnd(N, K, seed=2) / K ** 0.5, _rnd(B, N, H, W, seed=3)
+    xd = x.double()
+    kw = {}
+    if pro == "ln":
+        g, b = _rnd(K, seed=4), _rnd(K, seed=5)
+        xin = O.ln_chan(xd, g.double(), b.double())
+        kw["ln"] = (ops.chan_stats(dev(x)), dev(g), dev(b))
+        xs = dev(x)
+    elif pro == "ln3":
+        E = K // 3
+        g, b, vv = _rnd(K, seed=4), _rnd(K, seed=5), _rnd(B, E, H, W, seed=6)
+        parts = [O.ln_chan(xd[:, i * E:(i + 1) * E], g[i * E:(i + 1) * E].double(), b[i * E:(i + 1) * E].double()) * vv.double()
+                 for i in range(3)]
+        xin = torch.cat(parts, 1)
+        full = dev(torch.cat([x, vv], 1))
+        xs = full[:, :K]
+        kw["ln3_gate"] = (ops.chan_stats(xs, groups=3), dev(g), dev(b), full[:, K:])
+    elif pro == "muladd":
+        g, b, x1 = _rnd(K, seed=4), _rnd(K, seed=5), _rnd(B, K, H, W, seed=6)
+        xin = O.ln_chan(xd, g.double(), b.double()) * x1.double() + x1.double()
+        kw["ln_muladd"] = (ops.chan_stats(dev(x)), dev(g), dev(b), dev(x1))
+        xs = dev(x)
+    else:
+        xin, xs = xd, dev(x)
+    ref = torch.nn.functional.conv2d(xin, w.double().view(N, K, 1, 1)) + res.double()
+    got = ops.conv1x1(xs, dev(w), res=dev(res), want_stats=True, **kw)
+    assert rel_rms(got.cpu(), ref) < 2e-6
+    mu, var = ref.mean(1), ref.var(1, unbiased=False)
+    st = got._fdn_stats.cpu().view(B, 2, H, W)
+    tol = 1e-5 if N <= 160 else 1e-4          # N > 160: statistics come from the one-pass fdn_chan_stats kernel
+    assert rel_rms(st[:, 0], mu) < tol and rel_rms(st[:, 1], 1 / torch.sqrt(var + 1e-5)) < tol
+
+
+@pytest.mark.parametrize("C,N,H,W", [(86, 32, 24, 40), (345, 128, 16, 24), (64, 64, 46, 40), (43, 16, 8, 35)])
+def test_ffn_tail_fused_equals_reference(A, C, N, H, W):
+    """fdn_ffn_tail (gate + project_out + residual + statistics in one launch) against fp64, odd widths too."""
+    import ctypes
+    import fdn_hip
+    from fdn_hip import ops
+    B = 2
+    y, wd, w, res = _rnd(B, C, H, W, seed=1), _rnd(2 * C, 1, 3, 3, seed=2) * 0.3, _rnd(N, C, seed=3) / C ** 0.5, _rnd(B, N, H, W, seed=4)
+    F = torch.nn.functional
+    a, g = F.conv2d(y.double(), wd.double(), padding=1, groups=C).chunk(2, 1)
+    ref = F.conv2d(F.gelu(a) * g, w.double().view(N, C, 1, 1)) + res.double()
+    out = torch.empty(B, N, H, W, device="cuda:0")
+    st = torch.empty(B, 1, 2, H * W, device="cuda:0")
+    yd, wdd, wdv, rd = dev(y), dev(wd), dev(w), dev(res)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = fdn_hip.lib().fdn_ffn_tail(p(yd), p(wdd), p(wdv), p(rd), p(out), p(st), B, C, N, H, W, fdn_hip.stream())
+    assert rc == 0
+    assert rel_rms(out.cpu(), ref) < 3e-6
+    assert rel_rms(st.cpu().view(B, 2, H, W)[:, 0], ref.mean(1)) < 1e-5
+    assert rel_rms(ops.ffn_tail(yd, wdd, wdv, res=rd).cpu(), ref) < 3e-6         # whichever path the dispatcher picks
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W", [(64, 32, 24, 40), (3, 32, 16, 35), (12, 12, 9, 21), (32, 3, 16, 24), (128, 64, 8, 16)])
+def test_conv3x3_paths(A, Cin, Cout, H, W):
+    from fdn_hip import ops
+    x, w, b = _rnd(2, Cin, H, W, seed=1), _rnd(Cout, Cin, 3, 3, seed=2) / (3 * Cin ** 0.5), _rnd(Cout, seed=3)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    assert rel_rms(ops.conv2d(dev(x), dev(w), dev(b), pad=1).cpu(), ref) < 2e-6
+
+
+def test_fdsa_out_level1_equals_fallback(A):
+    """The register-resident FDSA tail and the statistics + GEMM fallback agree to rounding."""
+    from fdn_hip import ops
+    E, C, H, W, B = 38, 32, 24, 40, 2
+    o, w, g, b, res = _rnd(B, 4 * E, H, W, seed=1), _rnd(C, 3 * E, seed=2) / 10, _rnd(3 * E, seed=3), _rnd(3 * E, seed=4), _rnd(B, C, H, W, seed=5)
+    od = dev(o)
+    fast = ops.fdsa_out(od, dev(w), dev(g), dev(b), res=dev(res), want_stats=True)
+    assert fast is not None
+    slow = ops.conv1x1(od[:, :3 * E], dev(w), ln3_gate=(ops.chan_stats(od[:, :3 * E], groups=3), dev(g), dev(b), od[:, 3 * E:]),
+                       res=dev(res), want_stats=True)
+    assert rel_rms(fast.cpu(), slow.cpu()) < 1e-6
+    assert rel_rms(fast._fdn_stats.cpu(), slow._fdn_stats.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("H,W", [(738, 1282), (370, 642), (736, 1280), (1088, 1920), (18, 26)])
+def test_full_image_fft_sizes(A, H, W):
+    """rfft2 -> irfft2 round trip and forward parity with torch.fft (fp64) at the real sizes: 720p
+    (2^5*23 x 2^8*5), 1080p (2^6*17 x 2^7*15), fourier_fuse's 738 x 1282 (641 prime) and 370 x 642."""
+    from fdn_hip import ops
+    x = _rnd(1, 2, H, W, seed=H + W)
+    z = ops.rfft_rows(dev(x))
+    mag, ang = ops.fft_cols_fwd(z, True, True, rd_before=False, fix_real=True)
+    ref = torch.fft.rfft2(x.double())
+    assert rel_rms(mag.cpu(), ref.abs()) < 3e-6
+    zz = ops.fft_cols_inv_polar(mag, ang, H, W // 2 + 1)
+    back = ops.irfft_rows(zz, H, W, 2.0 / (H * W))
+    assert rel_rms(back.cpu(), x) < 1e-5
+
+
+def test_baseline_size_blocks_vs_oracle(A):
+    """BASELINE config-2 size (736 x 1280, one image): FDSA and FDFFN blocks against the CPU oracle."""
+    for name, cls, fn in (("fdsa_c32", A.FDSA, O.fdsa), ("fdffn_c32", A.FDFFN, O.fdffn)):
+        sd = fixture_weights(name, fixture(name)["shapes"])
+        m = load(cls(32), sd)
+        x = _rnd(1, 32, 736, 1280, seed=9)
+        with torch.no_grad():
+            got = m(dev(x)).cpu()
+            ref = fn(x, {"." + k: v for k, v in sd.items()}, "")
+        assert O.psnr(got, ref, peak=float(ref.abs().max())) > 110.0, name
+
+
+def test_baseline_size_batch_independence(A):
+    """Config-2 size: sharding the batch changes nothing, bit for bit (what the multi-GPU path relies on)."""
+    m = load(A.FDN(), fdn_weights(tame=0.03))
+    x = dev(torch.rand(2, 3, 736, 1280, generator=torch.Generator().manual_seed(11)))
+    r = dev(torch.tensor([[0.45], [0.65]]))
+    with torch.no_grad():
+        full = m(x, ratio_i=r)[0]
+        one = m(x[1:2].contiguous(), ratio_i=r[1:2].contiguous())[0]
+    assert torch.isfinite(full).all()
+    assert torch.equal(full[1:2], one)
