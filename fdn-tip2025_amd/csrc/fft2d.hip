@@ -233,6 +233,95 @@ __device__ float2* fft_run(float2* a, float2* b, const Plan& p, const float2* tw
 }
 
 // ------------------------------------------------------------------------------------------
+// In-place passes for the column kernels: every thread pulls the inputs of all its butterflies into
+// registers, the workgroup synchronises, then the outputs go back into the SAME LDS buffer at their
+// Stockham positions.  Halves the LDS footprint (no ping-pong buffer) so 2-3 workgroups share a CU.
+// Needs (N/R)*nseq <= NT*JMAX for every pass (checked on the host).
+// ------------------------------------------------------------------------------------------
+constexpr int EMAX = 36;                   // complex values a thread may hold across the barrier
+
+template <bool INV, int R>
+__device__ void fft_pass_inplace(float2* buf, int N, int Ns, int nseq, const float2* __restrict__ tw) {
+    constexpr int JMAX = EMAX / R;
+    const int T = N / R;
+    const int L = Ns * R;
+    const int tws = N / L, twr = N / R;
+    const int jobs = T * nseq;
+    float2 u[JMAX][R];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int job = threadIdx.x + NT * j;
+        if (job < jobs) {
+            const int i = job / nseq, s = job - i * nseq;
+            const int k = i % Ns;
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[j][r] = buf[s + (i + r * T) * nseq];
+            if (k) {
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[j][r] = cmul(u[j][r], twd<INV>(tw, r * k * tws));
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int job = threadIdx.x + NT * j;
+        if (job < jobs) {
+            const int i = job / nseq, s = job - i * nseq;
+            const int k = i % Ns;
+            float2* dp = buf + s + ((i - k) * R + k) * nseq;
+            if (R == 2) {
+                dp[0] = make_float2(u[j][0].x + u[j][1].x, u[j][0].y + u[j][1].y);
+                dp[Ns * nseq] = make_float2(u[j][0].x - u[j][1].x, u[j][0].y - u[j][1].y);
+            } else if (R == 4) {
+                const float2 a = make_float2(u[j][0].x + u[j][2].x, u[j][0].y + u[j][2].y);
+                const float2 b = make_float2(u[j][0].x - u[j][2].x, u[j][0].y - u[j][2].y);
+                const float2 c = make_float2(u[j][1].x + u[j][3].x, u[j][1].y + u[j][3].y);
+                const float2 d = make_float2(u[j][1].x - u[j][3].x, u[j][1].y - u[j][3].y);
+                const float2 jd = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+                dp[0] = make_float2(a.x + c.x, a.y + c.y);
+                dp[Ns * nseq] = make_float2(b.x + jd.x, b.y + jd.y);
+                dp[2 * Ns * nseq] = make_float2(a.x - c.x, a.y - c.y);
+                dp[3 * Ns * nseq] = make_float2(b.x - jd.x, b.y - jd.y);
+            } else {
+#pragma unroll
+                for (int o = 0; o < R; ++o) {
+                    float2 acc = u[j][0];
+#pragma unroll
+                    for (int r = 1; r < R; ++r) {
+                        const float2 w = twd<INV>(tw, ((r * o) % R) * twr);      // wave-uniform: LDS broadcast
+                        acc.x = fmaf(u[j][r].x, w.x, fmaf(-u[j][r].y, w.y, acc.x));
+                        acc.y = fmaf(u[j][r].x, w.y, fmaf(u[j][r].y, w.x, acc.y));
+                    }
+                    dp[o * Ns * nseq] = acc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <bool INV, bool BIG>
+__device__ void fft_run_inplace(float2* buf, const Plan& p, const float2* tw, int nseq) {
+    int Ns = 1;
+    __syncthreads();
+    for (int st = 0; st < p.nst; ++st) {
+        const int R = p.radix[st];
+        switch (R) {
+            case 2: fft_pass_inplace<INV, 2>(buf, p.N, Ns, nseq, tw); break;
+            case 3: fft_pass_inplace<INV, 3>(buf, p.N, Ns, nseq, tw); break;
+            case 4: fft_pass_inplace<INV, 4>(buf, p.N, Ns, nseq, tw); break;
+            case 5: fft_pass_inplace<INV, 5>(buf, p.N, Ns, nseq, tw); break;
+            case 7: fft_pass_inplace<INV, 7>(buf, p.N, Ns, nseq, tw); break;
+            case 17: if (BIG) fft_pass_inplace<INV, 17>(buf, p.N, Ns, nseq, tw); break;
+            case 23: if (BIG) fft_pass_inplace<INV, 23>(buf, p.N, Ns, nseq, tw); break;
+            default: break;
+        }
+        Ns *= R;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // rows: r2c
 // ------------------------------------------------------------------------------------------
 template <bool BIG>
@@ -347,13 +436,13 @@ struct ColArgs {
 
 enum { COL_FCAFFN = 0, COL_FWD = 1, COL_INV_POLAR = 2 };
 
-template <int MODE, bool BIG>
-__global__ __launch_bounds__(NT) void fft_cols_kernel(ColArgs a, const Plan p) {
+template <int MODE, bool BIG, bool INPL>
+__global__ __launch_bounds__(NT, (INPL ? 2 : 1)) void fft_cols_kernel(ColArgs a, const Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = a.H, Wf = a.Wf, tc = a.tc;
     float2* A = reinterpret_cast<float2*>(smem);
-    float2* Bf = A + (long)H * tc;
-    float2* twl = Bf + (long)H * tc;
+    float2* Bf = A + (long)H * tc;                       // unused when INPL
+    float2* twl = INPL ? Bf : Bf + (long)H * tc;
     for (int i = threadIdx.x; i < H; i += NT) twl[i] = p.tw[i];
     const int plane = blockIdx.y;
     const int col0 = blockIdx.x * tc;
@@ -378,7 +467,10 @@ __global__ __launch_bounds__(NT) void fft_cols_kernel(ColArgs a, const Plan p) {
         A[idx] = v;
     }
     float2* Z = A;
-    if (MODE != COL_INV_POLAR) Z = fft_run<false, BIG>(A, Bf, p, twl, tc, 1, tc, true);
+    if (MODE != COL_INV_POLAR) {
+        if (INPL) fft_run_inplace<false, BIG>(A, p, twl, tc);
+        else Z = fft_run<false, BIG>(A, Bf, p, twl, tc, 1, tc, true);
+    }
     float2* other = (Z == A) ? Bf : A;
 
     if (MODE == COL_FWD) {
@@ -417,7 +509,9 @@ __global__ __launch_bounds__(NT) void fft_cols_kernel(ColArgs a, const Plan p) {
             Z[idx] = cmul(r, make_float2(A_ * cs, -A_ * sn));           // |z| A e^{i(ang z - ph)}  :413-417
         }
     }
-    float2* Y = fft_run<true, BIG>(Z, other, p, twl, tc, 1, tc, true);
+    float2* Y = Z;
+    if (INPL) fft_run_inplace<true, BIG>(Z, p, twl, tc);
+    else Y = fft_run<true, BIG>(Z, other, p, twl, tc, 1, tc, true);
     for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
         const int h = idx / tc, c = idx - h * tc;
         if (c < ncol) zp[(long)h * Wf + col0 + c] = Y[idx];
@@ -456,24 +550,46 @@ int pick_rpb(int M) {
     return rpb;
 }
 
+// in-place passes possible: every radix has a register butterfly and its jobs fit NT*JMAX threads-slots
+int inplace_tc(const Plan& p, int H) {
+    for (int tc = 32; tc >= 8; tc >>= 1) {
+        if ((long)H * tc > (long)NT * 24) continue;               // keep the buffer <= 48 KiB: 3 workgroups per CU
+        bool ok = true;
+        for (int i = 0; i < p.nst && ok; ++i) {
+            const int R = p.radix[i];
+            if (!(R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 17 || R == 23)) ok = false;
+            else if ((long)(H / R) * tc > (long)NT * (EMAX / R)) ok = false;
+        }
+        if (ok) return tc;
+    }
+    return 0;
+}
+
+template <int MODE, bool BIG, bool INPL>
+int launch_cols_k(const ColArgs& a, const Plan& p, long planes, size_t lds, fdn_stream_t stream) {
+    if (int e = set_lds(fft_cols_kernel<MODE, BIG, INPL>, lds)) return e;
+    hipLaunchKernelGGL((fft_cols_kernel<MODE, BIG, INPL>), dim3(cdiv(a.Wf, a.tc), (unsigned)planes), dim3(NT), lds,
+                       static_cast<hipStream_t>(stream), a, p);
+    return fdn_launch_status();
+}
+
 template <int MODE>
 int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
     Plan p;
     if (!make_plan(a.H, a.H, &p)) return FDN_ERR_UNSUPPORTED;
-    a.tc = pick_tc(a.H);
-    if (a.tc == 0 || planes > 65535 * 32L) return FDN_ERR_UNSUPPORTED;
-    const size_t lds = (2UL * a.H * a.tc + a.H) * sizeof(float2);
     if (planes > 65535) return FDN_ERR_UNSUPPORTED;
-    if (plan_big(p)) {
-        if (int e = set_lds(fft_cols_kernel<MODE, true>, lds)) return e;
-        hipLaunchKernelGGL((fft_cols_kernel<MODE, true>), dim3(cdiv(a.Wf, a.tc), (unsigned)planes), dim3(NT), lds,
-                           static_cast<hipStream_t>(stream), a, p);
-    } else {
-        if (int e = set_lds(fft_cols_kernel<MODE, false>, lds)) return e;
-        hipLaunchKernelGGL((fft_cols_kernel<MODE, false>), dim3(cdiv(a.Wf, a.tc), (unsigned)planes), dim3(NT), lds,
-                           static_cast<hipStream_t>(stream), a, p);
+    const int itc = inplace_tc(p, a.H);
+    if (itc > 0) {
+        a.tc = itc;
+        const size_t lds = ((size_t)a.H * a.tc + a.H) * sizeof(float2);
+        return plan_big(p) ? launch_cols_k<MODE, true, true>(a, p, planes, lds, stream)
+                           : launch_cols_k<MODE, false, true>(a, p, planes, lds, stream);
     }
-    return fdn_launch_status();
+    a.tc = pick_tc(a.H);
+    if (a.tc == 0) return FDN_ERR_UNSUPPORTED;
+    const size_t lds = (2UL * a.H * a.tc + a.H) * sizeof(float2);
+    return plan_big(p) ? launch_cols_k<MODE, true, false>(a, p, planes, lds, stream)
+                       : launch_cols_k<MODE, false, false>(a, p, planes, lds, stream);
 }
 
 }  // namespace
