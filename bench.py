@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the per-GPU batch is split over")
     ap.add_argument("--scatter-gather", action="store_true", help="time RCCL scatter of inputs / gather of outputs too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -171,6 +172,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
 
+    from fdn_hip.pipeline import forward_streams
     net, lp = build_models(dev)
     x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
     B, _, H, W = x.shape
@@ -184,9 +186,7 @@ def main():
         if a.scatter_gather and world > 1:
             xin = torch.empty_like(x)
             dist.scatter(xin, root_in if rank == 0 else None, src=0)
-        with torch.no_grad():
-            ratio = lp(xin)
-            out = net(xin, ratio_i=ratio, device=dev)[0]
+        out = forward_streams(net, lp, xin, a.streams)          # LPNet -> FDN, batch halves on separate HIP streams
         if a.scatter_gather and world > 1:
             dist.gather(out, root_out if rank == 0 else None, dst=0)
         return out
@@ -217,7 +217,8 @@ def main():
     roof = None
     if rank == 0 and not a.no_roofline:
         with KernelTimer() as kt:
-            step()
+            with torch.no_grad():
+                net(x, ratio_i=lp(x), device=dev)                   # single stream: events bracket each launch
         agg = kt.summary()
         total_ms = sum(v[1] for v in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][1])
@@ -247,7 +248,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: FDN {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU fp32",
                        "global_batch": world * B, "parallelism": f"batch-shard x{world}", "weights": "synthetic (tamed 0.03) FDN + real LPNet",
-                       "scatter_gather_timed": bool(a.scatter_gather)},
+                       "scatter_gather_timed": bool(a.scatter_gather), "hip_streams": a.streams},
             "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * 4.0 * P * (ips / world) / (PEAK_HBM_GBS * 1e9),
                            "mfma_f32_frac": F_ALG_PER_PX * P * (ips / world) / (PEAK_F32_MFMA_TF * 1e12)},
             "roofline": roof, "cpu_baseline": cpu,

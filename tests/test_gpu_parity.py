@@ -322,3 +322,16 @@ def test_baseline_size_batch_independence(A):
         one = m(x[1:2].contiguous(), ratio_i=r[1:2].contiguous())[0]
     assert torch.isfinite(full).all()
     assert torch.equal(full[1:2], one)
+
+
+def test_forward_streams_bit_identical(A):
+    """Splitting the batch over HIP streams (fdn_hip.pipeline) returns exactly the single-stream result."""
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from fdn_hip.pipeline import forward_streams
+    net = load(A.FDN(), fdn_weights(tame=0.03))
+    lp = load(I_predict_net(), lpnet_weights())
+    x = dev(torch.rand(4, 3, 64, 96, generator=torch.Generator().manual_seed(21)))
+    one = forward_streams(net, lp, x, 1)
+    two = forward_streams(net, lp, x, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
