@@ -109,6 +109,22 @@ class KernelTimer:
         return agg
 
 
+def pmc_traffic_per_launch(prefix):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/*traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB * 1024; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for coalesced streaming reads on gfx950).  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))["kernels"]
+    n = sum(v["launches"] for k, v in d.items() if k.startswith(prefix))
+    if n == 0:
+        return None
+    gb = sum(2.0 * v["fetch_GB_raw"] + v["write_GB"] for k, v in d.items() if k.startswith(prefix))
+    return gb * 1e9 / n
+
+
 def usable_cores():
     """Host cores this process may actually use: min(cpu_count, affinity mask, cgroup cpu.max quota)."""
     n = os.cpu_count() or 1
@@ -226,7 +242,7 @@ def main():
         if name == "fdn_conv1x1":
             ach = fl / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TF,
-                    "traffic": None, "kernel": "conv1x1_kernel (fdn_conv1x1)", "launches": cnt, "avg_ms": ms / cnt,
+                    "traffic": pmc_traffic_per_launch("conv1x1"), "kernel": "conv1x1_kernel (fdn_conv1x1)", "launches": cnt, "avg_ms": ms / cnt,
                     "hbm_gbs_algorithmic": by / (ms * 1e-3) / 1e9, "share_of_step": ms / total_ms}
         else:
             roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
