@@ -183,7 +183,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FDN_BENCH_FORCE_DIST") == "1":      # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
@@ -193,17 +193,17 @@ def main():
     x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
     B, _, H, W = x.shape
     root_in = root_out = None
-    if a.scatter_gather and world > 1 and rank == 0:
+    if a.scatter_gather and dist is not None and rank == 0:
         root_in = [make_input(a.batch, a.height, a.width, dev, seed=1000 + r) for r in range(world)]
         root_out = [torch.empty_like(x) for _ in range(world)]
 
     def step():
         xin = x
-        if a.scatter_gather and world > 1:
+        if a.scatter_gather and dist is not None:
             xin = torch.empty_like(x)
             dist.scatter(xin, root_in if rank == 0 else None, src=0)
         out = forward_streams(net, lp, xin, a.streams)          # LPNet -> FDN, batch halves on separate HIP streams
-        if a.scatter_gather and world > 1:
+        if a.scatter_gather and dist is not None:
             dist.gather(out, root_out if rank == 0 else None, dst=0)
         return out
 
