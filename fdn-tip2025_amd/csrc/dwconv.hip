@@ -52,23 +52,30 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ x,
     }
 }
 
+// buffer addressing: per-lane byte offsets are computed once (invalid lanes get an out-of-range offset, which
+// loads 0 and drops stores) and the channel plane is a scalar offset, so plane walks cost no vector ALU work
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ rsrc_t mk_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+constexpr int HALO = (TH + 2) * LW;
+constexpr int HPT = (HALO + 255) / 256;   // 9 halo elements per thread
+
 // One workgroup produces the output pair (2m, 2m+1): both read input channel m for the GELU
 // branch, and (C+2m)/2, (C+2m+1)/2 for the gate branch (the same channel when C is even), so every
-// input plane is read once instead of twice.
-__global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      float* __restrict__ out, int C, int H, int W, int tiles_x) {
-    __shared__ float ta[TH + 2][LS];
-    __shared__ float tb[2][TH + 2][LS];
-    const int m = blockIdx.y, b = blockIdx.z;
-    const int j0 = 2 * m, j1 = 2 * m + 1;
-    const bool has1 = j1 < C;
-    const int cb0 = (C + j0) >> 1, cb1 = (C + j1) >> 1;     // grouped conv: output o reads input o/2
-    const bool same = cb1 == cb0 || !has1;
-    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    const long hw = (long)H * W;
-    load_halo(ta, x + ((long)b * C + m) * hw, H, W, ty0, tx0);
-    load_halo(tb[0], x + ((long)b * C + cb0) * hw, H, W, ty0, tx0);
-    if (!same) load_halo(tb[1], x + ((long)b * C + cb1) * hw, H, W, ty0, tx0);
+// input plane is read once instead of twice.  A thread walks 8 rows of one column with a sliding 3x3
+// window per plane (3 LDS reads per row and plane instead of 9).
+template <bool SAME>
+__device__ __forceinline__ void dw_gate_rows(const float* ta, const float* tb0, const float* tb1, const float* __restrict__ w, int C,
+                                             int j0, int j1, bool has1, int r0, int cx, rsrc_t rout, unsigned voff0,
+                                             unsigned row4, int rows_ok, unsigned plane0, unsigned plane1) {
     float wa0[9], wb0[9], wa1[9], wb1[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -77,21 +84,84 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
         wa1[i] = has1 ? w[j1 * 9 + i] : 0.f;
         wb1[i] = has1 ? w[(C + j1) * 9 + i] : 0.f;
     }
-    __syncthreads();
-    const int cx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
-    const int gx = tx0 + cx;
-    if (gx >= W) return;
-    float* d0 = out + ((long)b * C + j0) * hw;
-    float* d1 = out + ((long)b * C + j1) * hw;
-    const float (*t1)[LS] = same ? tb[0] : tb[1];
+    float a[3][3], p[3][3], q[3][3];
+    auto load_row = [&](int hr, int k) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            a[k][dx] = ta[hr * LS + cx + dx];
+            p[k][dx] = tb0[hr * LS + cx + dx];
+            if (!SAME) q[k][dx] = tb1[hr * LS + cx + dx];
+        }
+    };
+    load_row(r0, 0);
+    load_row(r0 + 1, 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int gy = ty0 + r0 + i;
-        if (gy < H) {
-            d0[(long)gy * W + gx] = gelu_fast(stencil(ta, r0 + i, cx, wa0)) * stencil(tb[0], r0 + i, cx, wb0);
-            if (has1) d1[(long)gy * W + gx] = gelu_fast(stencil(ta, r0 + i, cx, wa1)) * stencil(t1, r0 + i, cx, wb1);
+        load_row(r0 + i + 2, (i + 2) % 3);
+        float s0 = 0.f, g0 = 0.f, s1 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int k = (i + dy) % 3;
+                s0 = fmaf(wa0[dy * 3 + dx], a[k][dx], s0);
+                g0 = fmaf(wb0[dy * 3 + dx], p[k][dx], g0);
+                s1 = fmaf(wa1[dy * 3 + dx], a[k][dx], s1);
+                g1 = fmaf(wb1[dy * 3 + dx], SAME ? p[k][dx] : q[k][dx], g1);
+            }
+        if (i < rows_ok) {                                                   // wave-uniform
+            bstore(gelu_fast(s0) * g0, rout, voff0, plane0 + (unsigned)i * row4);
+            if (has1) bstore(gelu_fast(s1) * g1, rout, voff0, plane1 + (unsigned)i * row4);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      float* __restrict__ out, int C, int H, int W, int tiles_x) {
+    __shared__ float ta[(TH + 2) * LS];
+    __shared__ float tb[2][(TH + 2) * LS];
+    const int m = blockIdx.y, b = blockIdx.z;
+    const int j0 = 2 * m, j1 = 2 * m + 1;
+    const bool has1 = j1 < C;
+    const int cb0 = (C + j0) >> 1, cb1 = (C + j1) >> 1;     // grouped conv: output o reads input o/2
+    const bool same = cb1 == cb0 || !has1;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const unsigned hw4 = (unsigned)H * W * 4u;
+    const rsrc_t rin = mk_rsrc(x + (long)b * C * H * W, (unsigned)C * hw4);
+    const rsrc_t rout = mk_rsrc(out + (long)b * C * H * W, (unsigned)C * hw4);
+
+    float va[HPT], vb[HPT], vc[HPT];
+    int slot[HPT];
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int r = idx / LW, c = idx - r * LW;
+        const int y = ty0 - 1 + r, xx = tx0 - 1 + c;
+        const bool ok = idx < HALO && y >= 0 && y < H && xx >= 0 && xx < W;
+        const unsigned g = ok ? (unsigned)(y * W + xx) * 4u : OOB;
+        slot[i] = idx < HALO ? r * LS + c : -1;
+        va[i] = bload(rin, g, (unsigned)m * hw4);
+        vb[i] = bload(rin, g, (unsigned)cb0 * hw4);
+        vc[i] = same ? 0.f : bload(rin, g, (unsigned)cb1 * hw4);
+    }
+#pragma unroll
+    for (int i = 0; i < HPT; ++i)
+        if (i < HPT - 1 || slot[i] >= 0) {
+            ta[slot[i]] = va[i];
+            tb[0][slot[i]] = vb[i];
+            if (!same) tb[1][slot[i]] = vc[i];
+        }
+    __syncthreads();
+    const int cx = threadIdx.x & 63;
+    const int r0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 8;
+    const int gx = tx0 + cx, gy0 = ty0 + r0;
+    const unsigned voff0 = (gx < W && gy0 < H) ? (unsigned)(gy0 * W + gx) * 4u : OOB;
+    const int rows_ok = H - gy0;                              // rows of this wave inside the image (>= 8: all)
+    const unsigned row4 = (unsigned)W * 4u;
+    if (same)
+        dw_gate_rows<true>(ta, tb[0], tb[0], w, C, j0, j1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hw4, (unsigned)j1 * hw4);
+    else
+        dw_gate_rows<false>(ta, tb[0], tb[1], w, C, j0, j1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hw4, (unsigned)j1 * hw4);
 }
 
 // mul/add maps: per output channel c:  sum_tap w3[c][tap] * (sum_i w1[c][i] * img[i][p+tap])
@@ -149,6 +219,7 @@ extern "C" int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, 
 
 extern "C" int fdn_dwconv_gate(const float* x, const float* w, float* out, int B, int C, int H, int W, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w && out && B > 0 && C > 0 && H > 0 && W > 0 && C < 65536 && B < 65536);
+    FDN_CHECK_ARG(4ull * C * H * W < 0x80000000ull);          // one image's C planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     hipLaunchKernelGGL(dw_gate_kernel, dim3(tx * ty, (C + 1) / 2, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, out, C, H,
                        W, tx);

@@ -100,6 +100,26 @@ __device__ __forceinline__ void irfft8_row(const float2 (&X)[5], float (&x)[8]) 
 
 __device__ __forceinline__ float rsq(float v) { return __builtin_amdgcn_rsqf(v); }
 
+// buffer resources: per-lane byte offsets are computed once per workgroup (invalid lanes get an offset past
+// num_records, which loads as 0 and drops stores); the channel plane is a scalar offset, so walking planes
+// costs no vector ALU work (these kernels are VALU-issue bound, not HBM bound)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;       // images are limited to < 2 GB per tensor so that OOB (+ small immediates) stays out of range
+__device__ __forceinline__ rsrc_t mk_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore8(const float (&v)[8], rsrc_t r, unsigned voff, unsigned soff) {
+    u32x4 a, b;
+    a.x = __float_as_uint(v[0]); a.y = __float_as_uint(v[1]); a.z = __float_as_uint(v[2]); a.w = __float_as_uint(v[3]);
+    b.x = __float_as_uint(v[4]); b.y = __float_as_uint(v[5]); b.z = __float_as_uint(v[6]); b.w = __float_as_uint(v[7]);
+    __builtin_amdgcn_raw_buffer_store_b128(a, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(b, r, voff + 16u, soff, 0);
+}
+
 // ------------------------------------------------------------------------------------------
 // halo tiles: (TH+2) x (TW+2) floats of one plane, row stride HS (odd: thread (patch,row) reads hit
 // distinct banks); loaded through registers so the next channel's loads fly during the transforms
@@ -108,22 +128,26 @@ constexpr int HS = 65 + 2;         // 67: (r*67 + 8*px) mod 32 distinct for r<8,
 constexpr int HALO = (TH + 2) * (TW + 2);
 constexpr int HPT = (HALO + 255) / 256;   // 9 elements per thread
 
-__device__ __forceinline__ void halo_fetch(const float* __restrict__ src, int H, int W, int y0, int x0, float (&r)[HPT]) {
+// per-thread global byte offsets / LDS slots of its HPT halo elements (computed once, reused for every plane)
+__device__ __forceinline__ void halo_offsets(int H, int W, int y0, int x0, unsigned (&goff)[HPT], int (&slot)[HPT]) {
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
         const int idx = threadIdx.x + 256 * i;
         const int rr = idx / (TW + 2), cc = idx - rr * (TW + 2);
         const int y = y0 - 1 + rr, x = x0 - 1 + cc;
-        r[i] = (idx < HALO && y >= 0 && y < H && x >= 0 && x < W) ? src[(long)y * W + x] : 0.f;
+        const bool ok = idx < HALO && y >= 0 && y < H && x >= 0 && x < W;
+        goff[i] = ok ? (unsigned)(y * W + x) * 4u : OOB;
+        slot[i] = idx < HALO ? rr * HS + cc : -1;
     }
 }
-__device__ __forceinline__ void halo_stash(float* t, const float (&r)[HPT]) {
+__device__ __forceinline__ void halo_fetch(rsrc_t r, unsigned plane_off, const unsigned (&goff)[HPT], float (&v)[HPT]) {
 #pragma unroll
-    for (int i = 0; i < HPT; ++i) {
-        const int idx = threadIdx.x + 256 * i;
-        const int rr = idx / (TW + 2), cc = idx - rr * (TW + 2);
-        if (idx < HALO) t[rr * HS + cc] = r[i];
-    }
+    for (int i = 0; i < HPT; ++i) v[i] = bload(r, goff[i], plane_off);
+}
+__device__ __forceinline__ void halo_stash(float* t, const int (&slot)[HPT], const float (&v)[HPT]) {
+#pragma unroll
+    for (int i = 0; i < HPT - 1; ++i) t[slot[i]] = v[i];
+    if (slot[HPT - 1] >= 0) t[slot[HPT - 1]] = v[HPT - 1];
 }
 // 3x3 stencil for the 8 pixels of row `row`, columns col0..col0+7 of the tile (halo origin -1,-1)
 __device__ __forceinline__ void stencil_row8(const float* t, int row, int col0, const float (&w)[9], float (&o)[8]) {
@@ -153,21 +177,27 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     const int tid = threadIdx.x;
     const int e = blockIdx.y, b = blockIdx.z;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    const long hw = (long)H * W;
-    const long base = (long)b * 4 * E * hw;
+    const unsigned hw4 = (unsigned)H * W * 4u;                  // bytes per plane; 4E planes per image < 4 GB (checked by the host)
+    const long base = (long)b * 4 * E * H * W;
+    const rsrc_t rin = mk_rsrc(hidden + base, 4u * E * hw4);
+    const rsrc_t rout = mk_rsrc(out + base, 4u * E * hw4);
     const int patch = tid >> 3, rr = tid & 7;
     const int py = patch >> 3, px = patch & 7;
     const int gy = ty0 + py * 8 + rr, gx = tx0 + px * 8;
     const bool inside = gy < H && gx < W;          // patches are entirely inside or outside (H, W % 8 == 0)
+    const unsigned ooff = inside ? (unsigned)(gy * W + gx) * 4u : OOB;
 
+    unsigned goff[HPT];
+    int slot[HPT];
+    halo_offsets(H, W, ty0, tx0, goff, slot);
     float pre[HPT];
-    halo_fetch(hidden + base + (long)e * hw, H, W, ty0, tx0, pre);
-    halo_stash(halo[0], pre);
+    halo_fetch(rin, (unsigned)e * hw4, goff, pre);
+    halo_stash(halo[0], slot, pre);
     __syncthreads();
 
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        if (t < 3) halo_fetch(hidden + base + (long)((t + 1) * E + e) * hw, H, W, ty0, tx0, pre);
+        if (t < 3) halo_fetch(rin, (unsigned)((t + 1) * E + e) * hw4, goff, pre);
         float wk[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) wk[i] = dww[(t * E + e) * 9 + i];
@@ -178,11 +208,9 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
             rfft8_row(o8, sp);
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx) S[(t * NP + patch) * PS + kx * 8 + rr] = sp[kx];
-            halo_stash(halo[(t + 1) & 1], pre);
-        } else if (inside) {                                                // v_value goes straight out
-            float* dst = out + base + (long)(3 * E + e) * hw + (long)gy * W + gx;
-            *reinterpret_cast<float4*>(dst) = make_float4(o8[0], o8[1], o8[2], o8[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+            halo_stash(halo[(t + 1) & 1], slot, pre);
+        } else {                                                            // v_value goes straight out
+            bstore8(o8, rout, ooff, (unsigned)(3 * E + e) * hw4);
         }
         __syncthreads();
     }
@@ -233,18 +261,14 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     __syncthreads();
 
     // ---- inverse rows, 32-byte segments straight to global (out1|out2|out3) --------------------------
-    if (inside) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            float2 x[5];
+    for (int t = 0; t < 3; ++t) {
+        float2 x[5];
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) x[kx] = S[(t * NP + patch) * PS + kx * 8 + rr];
-            float r[8];
-            irfft8_row(x, r);
-            float* dst = out + base + (long)(t * E + e) * hw + (long)gy * W + gx;
-            *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(r[4], r[5], r[6], r[7]);
-        }
+        for (int kx = 0; kx < 5; ++kx) x[kx] = S[(t * NP + patch) * PS + kx * 8 + rr];
+        float r[8];
+        irfft8_row(x, r);
+        bstore8(r, rout, ooff, (unsigned)(t * E + e) * hw4);
     }
 }
 
@@ -270,29 +294,34 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
     const int tid = threadIdx.x;
     const int cbase = blockIdx.y * CPB, b = blockIdx.z;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    const long hw = (long)H * W;
+    const unsigned hw4 = (unsigned)H * W * 4u;                  // bytes per plane; Hd planes per image < 4 GB (checked by the host)
+    const rsrc_t rin = mk_rsrc(x + (long)b * Hd * H * W, (unsigned)Hd * hw4);
+    const rsrc_t rout = mk_rsrc(out + (long)b * Hd * H * W, (unsigned)Hd * hw4);
     const int patch = tid >> 3, rr = tid & 7;
     const int py = patch >> 3, px = patch & 7;
     const int gy = ty0 + py * 8 + rr, gx = tx0 + px * 8;
+    const unsigned ooff = (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOB;
 
+    unsigned goff[HPT2];
+    int slot[HPT2];
+#pragma unroll
+    for (int i = 0; i < HPT2; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx / (TW + 4), cc = idx - r * (TW + 4);
+        const int y = ty0 - 2 + r, xx = tx0 - 2 + cc;
+        const bool ok = idx < HALO2 && y >= 0 && y < H && xx >= 0 && xx < W;
+        goff[i] = ok ? (unsigned)(y * W + xx) * 4u : OOB;
+        slot[i] = idx < HALO2 ? r * LS2 + cc : -1;
+    }
     float pre[HPT2];
     auto fetch = [&](int c) {
-        const float* src = x + ((long)b * Hd + c) * hw;
 #pragma unroll
-        for (int i = 0; i < HPT2; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx / (TW + 4), cc = idx - r * (TW + 4);
-            const int y = ty0 - 2 + r, xx = tx0 - 2 + cc;
-            pre[i] = (idx < HALO2 && y >= 0 && y < H && xx >= 0 && xx < W) ? src[(long)y * W + xx] : 0.f;
-        }
+        for (int i = 0; i < HPT2; ++i) pre[i] = bload(rin, goff[i], (unsigned)c * hw4);
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < HPT2; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx / (TW + 4), cc = idx - r * (TW + 4);
-            if (idx < HALO2) tin[r * LS2 + cc] = pre[i];
-        }
+        for (int i = 0; i < HPT2 - 1; ++i) tin[slot[i]] = pre[i];
+        if (slot[HPT2 - 1] >= 0) tin[slot[HPT2 - 1]] = pre[HPT2 - 1];
     };
     fetch(cbase);
     stash();
@@ -403,15 +432,15 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
         __syncthreads();
 
         // ---- C: inverse rows + spatial branch, 32-byte segments to global --------------------------------
-        if (gy < H && gx < W) {
+        {
             float2 xk[5];
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx) xk[kx] = S[patch * PS + kx * 8 + rr];
             float r[8];
             irfft8_row(xk, r);
-            float* dst = out + ((long)b * Hd + c) * hw + (long)gy * W + gx;
-            *reinterpret_cast<float4*>(dst) = make_float4(r[0] + sp[0], r[1] + sp[1], r[2] + sp[2], r[3] + sp[3]);   // :470
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(r[4] + sp[4], r[5] + sp[5], r[6] + sp[6], r[7] + sp[7]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += sp[j];                                                              // :470
+            bstore8(r, rout, ooff, (unsigned)c * hw4);
         }
         __syncthreads();                                          // S, mid, filt are rewritten by the next channel
     }
@@ -424,6 +453,7 @@ extern "C" int fdn_fdsa_core(const float* hidden, const float* dw_w, const float
     FDN_CHECK_ARG(hidden && dw_w && fft_w && out && B > 0 && E > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0 && E < 65536 && B < 65536);
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    FDN_CHECK_ARG(16ull * E * H * W < 0x80000000ull);          // one image's 4E planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     hipLaunchKernelGGL(fdsa_core_kernel, dim3(tx * ty, E, B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
                        fft_w, out, E, H, W, tx);
@@ -435,6 +465,7 @@ extern "C" int fdn_fdffn_mid(const float* x, const float* w0, const float* w2, c
     FDN_CHECK_ARG(x && w0 && w2 && ffta && fftp && out && B > 0 && Hd > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0 && Hd < 65536 && B < 65536);
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    FDN_CHECK_ARG(4ull * Hd * H * W < 0x80000000ull);          // one image's Hd planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     hipLaunchKernelGGL(fdffn_mid_kernel, dim3(tx * ty, (Hd + CPB - 1) / CPB, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w0, w2,
                        ffta, fftp, out, Hd, H, W, tx);

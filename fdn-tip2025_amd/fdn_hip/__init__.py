@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libfdn_hip.so")
+_LIB_PATH = os.environ.get("FDN_HIP_LIB") or os.path.join(_HERE, "libfdn_hip.so")   # override: A/B builds of the same ABI
 _lib = None
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
