@@ -152,14 +152,14 @@ def fdffn_mid(x, w0, w2, ffta, fftp):
     return out
 
 
-def ffn_tail(y, dw_w, w, res=None, want_stats=False):
+def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None):
     """gate + project_out + residual (+ next LayerNorm statistics) in one launch (fdn_ffn_tail)."""
     B, C, H, W = y.shape
     N = w.shape[0]
-    # measured on MI355X (tools/bench_kernels.py tail): the fused launch wins where the projection is wide
-    # (level 3, and level-2 FCAFFN); at level 1 the stencil VALU work per MFMA is too high and the
-    # two-launch form (gate kernel + MFMA GEMM) is ~15 % faster
-    fused = N == 128 or (N == 64 and C <= 64)
+    # measured on MI355X (tools/bench_kernels.py tail, B=8 720p): since the gate kernel walks a sliding 3x3
+    # window (1.28 ms at level 1) the two-launch form (gate kernel + MFMA GEMM) beats the fused launch at
+    # every level (L3 FDFFN 1.12 vs 1.31 ms, L1 2.50 vs 3.90 ms); the fused kernel stays selectable
+    fused = mode == "fused"
     if not fused:
         g = dwconv_gate(y, dw_w)
         return conv1x1(g, w, res=res, want_stats=want_stats)
