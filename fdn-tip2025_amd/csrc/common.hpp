@@ -43,6 +43,26 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// sin and cos together, ~1 ulp for |x| < 8192 (three-constant Cody-Waite reduction by pi/2, then the classic
+// single-precision minimax polynomials on [-pi/4, pi/4]); larger arguments take the library path.  The
+// library sincosf costs ~4x the instructions because it carries the Payne-Hanek reduction inline.
+__device__ __forceinline__ void fdn_sincos(float x, float* sn, float* cs) {
+    if (!(fabsf(x) < 8192.0f)) { sincosf(x, sn, cs); return; }
+    const float k = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(k, -1.5707962513e+0f, x);
+    r = fmaf(k, -7.5497894159e-08f, r);
+    r = fmaf(k, -5.3903029534e-15f, r);
+    const float r2 = r * r;
+    const float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    const float s0 = fmaf(r * r2, ps, r);
+    const float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    const float c0 = fmaf(r2 * r2, pc, fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k;
+    const float a = (q & 1) ? c0 : s0, b = (q & 1) ? s0 : c0;
+    *sn = (q & 2) ? -a : a;
+    *cs = ((q + 1) & 2) ? -b : b;
+}
+
 // replace_denormals on one component: (-1e-10, 1e-10) incl. +-0 -> +1e-10 (FDN_arch.py:548-553)
 __device__ __forceinline__ float rd1(float v) { return (v < 1e-10f && v > -1e-10f) ? 1e-10f : v; }
 

@@ -99,8 +99,43 @@ __device__ __forceinline__ float2 twd(const float2* __restrict__ tw, int idx) {
     return INV ? make_float2(w.x, -w.y) : w;
 }
 
-// odd-prime pass with the whole radix-R butterfly in registers (naive DFT_R, R^2 complex MACs);
-// the R roots of unity sit in registers too, so the inner loop has no memory traffic at all
+// DFT_R of an odd R in registers, using the conjugate symmetry of the roots: with a_r = u_r + u_{R-r},
+// b_r = u_r - u_{R-r} (r = 1..h, h = (R-1)/2) and w = e^{-+2 pi i m/R},
+//   X_o = P_o + Q_o,  X_{R-o} = P_o - Q_o,  P_o = u_0 + sum_r a_r Re(w_{ro}),  Q_o = i sum_r b_r Im(w_{ro})
+// i.e. (R-1)^2 real FMAs instead of the 4 (R-1) R of the plain complex matrix product (3.4x fewer for R = 23),
+// and only h roots live in registers.  `wR[m-1]` = w_m for m = 1..h.
+template <int R>
+__device__ __forceinline__ void dft_odd(float2 (&u)[R], const float2 (&wR)[(R - 1) / 2]) {
+    constexpr int h = (R - 1) / 2;
+    float2 a[h], b[h];
+    float2 x0 = u[0];
+#pragma unroll
+    for (int r = 1; r <= h; ++r) {
+        a[r - 1] = make_float2(u[r].x + u[R - r].x, u[r].y + u[R - r].y);
+        b[r - 1] = make_float2(u[r].x - u[R - r].x, u[r].y - u[R - r].y);
+        x0.x += a[r - 1].x;
+        x0.y += a[r - 1].y;
+    }
+#pragma unroll
+    for (int o = 1; o <= h; ++o) {
+        float2 P = u[0], Q = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 1; r <= h; ++r) {
+            const int m = (r * o) % R;
+            const float wx = wR[(m <= h ? m : R - m) - 1].x;
+            const float wy = (m <= h) ? wR[m - 1].y : -wR[R - m - 1].y;
+            P.x = fmaf(a[r - 1].x, wx, P.x);
+            P.y = fmaf(a[r - 1].y, wx, P.y);
+            Q.x = fmaf(-b[r - 1].y, wy, Q.x);
+            Q.y = fmaf(b[r - 1].x, wy, Q.y);
+        }
+        u[o] = make_float2(P.x + Q.x, P.y + Q.y);
+        u[R - o] = make_float2(P.x - Q.x, P.y - Q.y);
+    }
+    u[0] = x0;
+}
+
+// odd-prime pass with the whole radix-R butterfly in registers
 template <bool INV, int R>
 __device__ void fft_pass_reg(const float2* src, float2* dst, int N, int Ns, int nseq, int ss, int es, bool seq_fast,
                              const float2* __restrict__ tw, int tab_mul) {
@@ -108,9 +143,9 @@ __device__ void fft_pass_reg(const float2* src, float2* dst, int N, int Ns, int 
     const int L = Ns * R;
     const int tws = tab_mul * (N / L);
     const int twr = tab_mul * (N / R);
-    float2 wR[R];
+    float2 wR[(R - 1) / 2];
 #pragma unroll
-    for (int t = 0; t < R; ++t) wR[t] = twd<INV>(tw, t * twr);
+    for (int t = 1; t <= (R - 1) / 2; ++t) wR[t - 1] = twd<INV>(tw, t * twr);
     const int jobs = T * nseq;
     for (int job = threadIdx.x; job < jobs; job += NT) {
         int i, s;
@@ -127,17 +162,9 @@ __device__ void fft_pass_reg(const float2* src, float2* dst, int N, int Ns, int 
 #pragma unroll
             for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twd<INV>(tw, r * k * tws));
         }
+        dft_odd<R>(u, wR);
 #pragma unroll
-        for (int o = 0; o < R; ++o) {
-            float2 acc = u[0];
-#pragma unroll
-            for (int r = 1; r < R; ++r) {
-                const float2 w = wR[(r * o) % R];
-                acc.x = fmaf(u[r].x, w.x, fmaf(-u[r].y, w.y, acc.x));
-                acc.y = fmaf(u[r].x, w.y, fmaf(u[r].y, w.x, acc.y));
-            }
-            dp[(j + o * Ns) * es] = acc;
-        }
+        for (int o = 0; o < R; ++o) dp[(j + o * Ns) * es] = u[o];
     }
 }
 
@@ -283,18 +310,13 @@ __device__ void fft_pass_inplace(float2* buf, int N, int Ns, int nseq, const flo
                 dp[Ns * nseq] = make_float2(b.x + jd.x, b.y + jd.y);
                 dp[2 * Ns * nseq] = make_float2(a.x - c.x, a.y - c.y);
                 dp[3 * Ns * nseq] = make_float2(b.x - jd.x, b.y - jd.y);
-            } else {
+            } else if constexpr (R % 2 == 1) {
+                float2 wR[(R - 1) / 2];                                           // wave-uniform: LDS broadcast
 #pragma unroll
-                for (int o = 0; o < R; ++o) {
-                    float2 acc = u[j][0];
+                for (int t = 1; t <= (R - 1) / 2; ++t) wR[t - 1] = twd<INV>(tw, t * twr);
+                dft_odd<R>(u[j], wR);
 #pragma unroll
-                    for (int r = 1; r < R; ++r) {
-                        const float2 w = twd<INV>(tw, ((r * o) % R) * twr);      // wave-uniform: LDS broadcast
-                        acc.x = fmaf(u[j][r].x, w.x, fmaf(-u[j][r].y, w.y, acc.x));
-                        acc.y = fmaf(u[j][r].x, w.y, fmaf(u[j][r].y, w.x, acc.y));
-                    }
-                    dp[o * Ns * nseq] = acc;
-                }
+                for (int o = 0; o < R; ++o) dp[o * Ns * nseq] = u[j][o];
             }
         }
     }
@@ -335,6 +357,7 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < W; i += NT) twl[i] = p.tw[i];
     const long row0 = (long)blockIdx.x * rpb;
     const int nrow = (int)min((long)rpb, R - row0);
+#pragma unroll 8
     for (int idx = threadIdx.x; idx < rpb * M; idx += NT) {
         const int s = idx / M, m = idx - s * M;
         A[idx] = (s < nrow) ? reinterpret_cast<const float2*>(in + (row0 + s) * W)[m] : make_float2(0.f, 0.f);
@@ -342,6 +365,7 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
     float2* Z = fft_run<false, BIG>(A, Bf, p, twl, rpb, M, 1, false);
     // split: X[k] = E[k] + W_N^k O[k],  E = (Z[k]+conj Z[M-k])/2,  O = -i (Z[k]-conj Z[M-k])/2
     const int tw1 = p.tab_mul / 2;              // table is W_W^t:  tab_mul = W / M = 2  -> stride 1
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < nrow * Wf; idx += NT) {
         const int s = idx / Wf, k = idx - s * Wf;
         const float2 zk = Z[s * M + (k == M ? 0 : k)];
@@ -376,6 +400,7 @@ __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict
     const long row0 = (long)blockIdx.x * rpb;
     const int nrow = (int)min((long)rpb, R - row0);
     const int tw1 = p.tab_mul / 2;
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < rpb * M; idx += NT) {
         const int s = idx / M, k = idx - s * M;
         float2 z = make_float2(0.f, 0.f);
@@ -395,6 +420,7 @@ __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict
         A[idx] = z;
     }
     float2* Z = fft_run<true, BIG>(A, Bf, p, twl, rpb, M, 1, false);
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < nrow * M; idx += NT) {
         const int s = idx / M, m = idx - s * M;
         const long row = row0 + s;
@@ -417,10 +443,10 @@ struct ColArgs {
     // spectrum planes: [planes][H][Wf] complex
     float2* z;                 // in/out (FCAFFN), in (fwd), out (inv polar)
     int H, Wf, C;              // C = channels per batch item (plane = b*C + c)
-    int tc;
+    int tc, tcs;               // columns per workgroup (a power of two) and its log2
+    long planes;               // total planes (a multiple of C)
     // FCAFFN modulation (FDN_arch.py:412-417)
-    const float* amp;          // [B][3][H][Wf]
-    const float* pha;          // [B][3][H][Wf]
+    const float4* guide;       // [B][H][Wf][2] float4: (amp0, amp1, amp2, pha0), (pha1, pha2, -, -)  (fdn_pack_guidance)
     const float* wxa;          // [C][3]
     const float* wxp;          // [C][3]
     // forward outputs (real planes [planes][H][Wf])
@@ -444,27 +470,66 @@ __global__ __launch_bounds__(NT, (INPL ? 2 : 1)) void fft_cols_kernel(ColArgs a,
     float2* Bf = A + (long)H * tc;                       // unused when INPL
     float2* twl = INPL ? Bf : Bf + (long)H * tc;
     for (int i = threadIdx.x; i < H; i += NT) twl[i] = p.tw[i];
-    const int plane = blockIdx.y;
-    const int col0 = blockIdx.x * tc;
+    // XCD-aware work order: workgroups i and i+8 share an XCD (round-robin dispatch), so each XCD walks a
+    // contiguous range of work items ordered (batch, column tile, channel): consecutive workgroups of an XCD
+    // read the same guidance records (shared by all C channels of a batch item) out of that XCD's L2
+    int plane, col0;
+    {
+        const int ntile = (Wf + tc - 1) / tc;
+        const long total = (long)ntile * a.planes, per_xcd = (total + 7) / 8;
+        const long w = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (w >= total) return;                                              // uniform: before any barrier
+        const int C = a.C;
+        const long grp = w / C;
+        const int ch = (int)(w - grp * C);
+        plane = (int)(grp / ntile) * C + ch;
+        col0 = (int)(grp % ntile) * tc;
+    }
     const int ncol = min(tc, Wf - col0);
     float2* zp = a.z + (long)plane * H * Wf;
 
-    // ---- load --------------------------------------------------------------------------------
-    for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
-        const int h = idx / tc, c = idx - h * tc;
-        float2 v = make_float2(0.f, 0.f);
-        if (c < ncol) {
-            if (MODE == COL_INV_POLAR) {
-                const long o = ((long)plane * a.Hin + h) * a.Wfin + col0 + c;
-                const float m = a.in_mag[o], ph = a.in_pha[o];
-                float sn, cs;
-                sincosf(ph, &sn, &cs);
-                v = make_float2(m * cs, m * sn);                                  // FDN_arch.py:95-97
-            } else {
-                v = zp[(long)h * Wf + col0 + c];
+    // ---- load: batches of independent requests (a plain loop would pay one memory round trip per element) ----
+    const int per = H * tc, tcs = a.tcs, tcm = tc - 1;                 // tc is a power of two
+    if (MODE == COL_INV_POLAR) {
+        constexpr int U = 4;
+        for (int base = threadIdx.x; base < per; base += NT * U) {
+            float mg[U], ph[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + NT * u, h = idx >> tcs, c = idx & tcm;
+                mg[u] = 0.f; ph[u] = 0.f;
+                if (idx < per && c < ncol) {
+                    const long o = ((long)plane * a.Hin + h) * a.Wfin + col0 + c;
+                    mg[u] = a.in_mag[o];
+                    ph[u] = a.in_pha[o];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + NT * u;
+                if (idx < per) {
+                    float sn, cs;
+                    fdn_sincos(ph[u], &sn, &cs);
+                    A[idx] = make_float2(mg[u] * cs, mg[u] * sn);                  // FDN_arch.py:95-97
+                }
             }
         }
-        A[idx] = v;
+    } else {
+        constexpr int U = 12;        // two round trips for 24 elements per thread (H * tc = 5888)
+        for (int base = threadIdx.x; base < per; base += NT * U) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + NT * u, h = idx >> tcs, c = idx & tcm;
+                v[u] = make_float2(0.f, 0.f);
+                if (idx < per && c < ncol) v[u] = zp[(long)h * Wf + col0 + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + NT * u;
+                if (idx < per) A[idx] = v[u];
+            }
+        }
     }
     float2* Z = A;
     if (MODE != COL_INV_POLAR) {
@@ -475,8 +540,9 @@ __global__ __launch_bounds__(NT, (INPL ? 2 : 1)) void fft_cols_kernel(ColArgs a,
 
     if (MODE == COL_FWD) {
         const bool evenH = (H % 2) == 0;
-        for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
-            const int h = idx / tc, c = idx - h * tc;
+#pragma unroll 2
+        for (int idx = threadIdx.x; idx < per; idx += NT) {
+            const int h = idx >> tcs, c = idx & tcm;
             if (c >= ncol) continue;
             float2 v = Z[idx];
             const int col = col0 + c;
@@ -493,27 +559,39 @@ __global__ __launch_bounds__(NT, (INPL ? 2 : 1)) void fft_cols_kernel(ColArgs a,
         const int b = plane / a.C, ch = plane - b * a.C;
         const float wa0 = a.wxa[ch * 3], wa1 = a.wxa[ch * 3 + 1], wa2 = a.wxa[ch * 3 + 2];
         const float wp0 = a.wxp[ch * 3], wp1 = a.wxp[ch * 3 + 1], wp2 = a.wxp[ch * 3 + 2];
-        const long gs = (long)H * Wf;
-        const float* ampb = a.amp + (long)b * 3 * gs;
-        const float* phab = a.pha + (long)b * 3 * gs;
-        for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
-            const int h = idx / tc, c = idx - h * tc;
-            if (c >= ncol) continue;
-            const long o = (long)h * Wf + col0 + c;
-            const float A_ = wa0 * ampb[o] + wa1 * ampb[gs + o] + wa2 * ampb[2 * gs + o];      // conv1_xa(x_high)
-            const float ph = wp0 * phab[o] + wp1 * phab[gs + o] + wp2 * phab[2 * gs + o];      // conv1_xp(xp2)
-            float sn, cs;
-            sincosf(ph, &sn, &cs);
-            const float2 v = Z[idx];
-            const float2 r = make_float2(rd1(v.x), rd1(v.y));                                   // :412
-            Z[idx] = cmul(r, make_float2(A_ * cs, -A_ * sn));           // |z| A e^{i(ang z - ph)}  :413-417
+        const float4* gb = a.guide + (long)b * H * Wf * 2;
+        constexpr int U = 12;       // registers are free here (the FFT passes are separate calls)
+        for (int base = threadIdx.x; base < per; base += NT * U) {
+            float4 g0[U], g1[U];                                   // one 32-byte record per bin: rows of a tile are contiguous
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + NT * u, h = idx >> tcs, c = idx & tcm;
+                const bool ok = idx < per && c < ncol;
+                const long o = ok ? (long)h * Wf + col0 + c : 0;
+                g0[u] = gb[2 * o];
+                g1[u] = gb[2 * o + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + NT * u, c = idx & tcm;
+                if (idx < per && c < ncol) {
+                    const float A_ = wa0 * g0[u].x + wa1 * g0[u].y + wa2 * g0[u].z;       // conv1_xa(x_high)
+                    const float ph = wp0 * g0[u].w + wp1 * g1[u].x + wp2 * g1[u].y;       // conv1_xp(xp2)
+                    float sn, cs;
+                    fdn_sincos(ph, &sn, &cs);
+                    const float2 v = Z[idx];
+                    const float2 r = make_float2(rd1(v.x), rd1(v.y));                       // :412
+                    Z[idx] = cmul(r, make_float2(A_ * cs, -A_ * sn));   // |z| A e^{i(ang z - ph)}  :413-417
+                }
+            }
         }
     }
     float2* Y = Z;
     if (INPL) fft_run_inplace<true, BIG>(Z, p, twl, tc);
     else Y = fft_run<true, BIG>(Z, other, p, twl, tc, 1, tc, true);
-    for (int idx = threadIdx.x; idx < H * tc; idx += NT) {
-        const int h = idx / tc, c = idx - h * tc;
+#pragma unroll 8
+    for (int idx = threadIdx.x; idx < per; idx += NT) {
+        const int h = idx >> tcs, c = idx & tcm;
         if (c < ncol) zp[(long)h * Wf + col0 + c] = Y[idx];
     }
 }
@@ -566,9 +644,13 @@ int inplace_tc(const Plan& p, int H) {
 }
 
 template <int MODE, bool BIG, bool INPL>
-int launch_cols_k(const ColArgs& a, const Plan& p, long planes, size_t lds, fdn_stream_t stream) {
+int launch_cols_k(ColArgs a, const Plan& p, long planes, size_t lds, fdn_stream_t stream) {
+    a.planes = planes;
+    if (a.C <= 0 || planes % a.C != 0) a.C = 1;
     if (int e = set_lds(fft_cols_kernel<MODE, BIG, INPL>, lds)) return e;
-    hipLaunchKernelGGL((fft_cols_kernel<MODE, BIG, INPL>), dim3(cdiv(a.Wf, a.tc), (unsigned)planes), dim3(NT), lds,
+    const long total = (long)cdiv(a.Wf, a.tc) * planes, per_xcd = (total + 7) / 8;
+    if (per_xcd * 8 > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((fft_cols_kernel<MODE, BIG, INPL>), dim3((unsigned)(per_xcd * 8)), dim3(NT), lds,
                        static_cast<hipStream_t>(stream), a, p);
     return fdn_launch_status();
 }
@@ -577,16 +659,17 @@ template <int MODE>
 int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
     Plan p;
     if (!make_plan(a.H, a.H, &p)) return FDN_ERR_UNSUPPORTED;
-    if (planes > 65535) return FDN_ERR_UNSUPPORTED;
     const int itc = inplace_tc(p, a.H);
     if (itc > 0) {
         a.tc = itc;
+        a.tcs = __builtin_ctz(itc);
         const size_t lds = ((size_t)a.H * a.tc + a.H) * sizeof(float2);
         return plan_big(p) ? launch_cols_k<MODE, true, true>(a, p, planes, lds, stream)
                            : launch_cols_k<MODE, false, true>(a, p, planes, lds, stream);
     }
     a.tc = pick_tc(a.H);
     if (a.tc == 0) return FDN_ERR_UNSUPPORTED;
+    a.tcs = __builtin_ctz(a.tc);
     const size_t lds = (2UL * a.H * a.tc + a.H) * sizeof(float2);
     return plan_big(p) ? launch_cols_k<MODE, true, false>(a, p, planes, lds, stream)
                        : launch_cols_k<MODE, false, false>(a, p, planes, lds, stream);
@@ -641,13 +724,34 @@ extern "C" int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane
     return fdn_launch_status();
 }
 
-extern "C" int fdn_fft_cols_fcaffn(float* z, const float* amp, const float* pha, const float* wxa, const float* wxp, int B,
-                                   int C, int H, int Wf, fdn_stream_t stream) {
-    FDN_CHECK_ARG(z && amp && pha && wxa && wxp && B > 0 && C > 0 && H > 0 && Wf > 0);
+__global__ __launch_bounds__(256) void pack_guidance_kernel(const float* __restrict__ amp, const float* __restrict__ pha,
+                                                            float4* __restrict__ out, long bins, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // (b, h, w) flat
+    if (i >= total) return;
+    const long b = i / bins, o = i - b * bins;
+    const float* ap = amp + b * 3 * bins + o;
+    const float* pp = pha + b * 3 * bins + o;
+    out[2 * i] = make_float4(ap[0], ap[bins], ap[2 * bins], pp[0]);
+    out[2 * i + 1] = make_float4(pp[bins], pp[2 * bins], 0.f, 0.f);
+}
+
+extern "C" int fdn_pack_guidance(const float* amp, const float* pha, float* packed, int B, int H, int Wf, fdn_stream_t stream) {
+    FDN_CHECK_ARG(amp && pha && packed && B > 0 && H > 0 && Wf > 0);
+    FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 15) == 0);
+    const long bins = (long)H * Wf, total = bins * B;
+    hipLaunchKernelGGL(pack_guidance_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), amp,
+                       pha, reinterpret_cast<float4*>(packed), bins, total);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_fft_cols_fcaffn(float* z, const float* guide, const float* wxa, const float* wxp, int B, int C, int H,
+                                   int Wf, fdn_stream_t stream) {
+    FDN_CHECK_ARG(z && guide && wxa && wxp && B > 0 && C > 0 && H > 0 && Wf > 0);
+    FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(guide) & 15) == 0);
     ColArgs a = {};
     a.z = reinterpret_cast<float2*>(z);
     a.H = H; a.Wf = Wf; a.C = C;
-    a.amp = amp; a.pha = pha; a.wxa = wxa; a.wxp = wxp;
+    a.guide = reinterpret_cast<const float4*>(guide); a.wxa = wxa; a.wxp = wxp;
     return launch_cols<COL_FCAFFN>(a, (long)B * C, stream);
 }
 

@@ -37,6 +37,9 @@ class FdnHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 3          # include/fdn_hip.h: bumped on any signature change
+
+
 def lib_path():
     return _LIB_PATH
 
@@ -52,6 +55,10 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.fdn_error_string.restype = ctypes.c_char_p
         _lib.fdn_abi_version.restype = ctypes.c_int
+        if _lib.fdn_abi_version() != ABI_VERSION:
+            v = _lib.fdn_abi_version()
+            _lib = None
+            raise ImportError(f"{_LIB_PATH} has ABI version {v}, this binding needs {ABI_VERSION}: rebuild with build.sh")
     return _lib
 
 

@@ -223,10 +223,25 @@ def irfft_rows(z, H, W, scale, res=None, alpha=0.0, out=None):
     return out
 
 
+def pack_guidance(amp, pha):
+    """(amp, pha) [B,3,H,Wf] -> one 32-byte record per bin [B,H,Wf,8] (fdn_pack_guidance).  The guidance of a
+    level is shared by all its encoder blocks, so the packed copy is memoised on the amp tensor object."""
+    cached = getattr(amp, "_fdn_packed", None)
+    if cached is not None and cached[0] is pha:
+        return cached[1]
+    B, _, H, Wf = amp.shape
+    out = torch.empty((B, H, Wf, 8), device=amp.device, dtype=torch.float32)
+    check(lib().fdn_pack_guidance(_flat(amp, "amp"), _flat(pha, "pha"), _flat(out, "packed"), B, H, Wf, stream()),
+          "fdn_pack_guidance")
+    amp._fdn_packed = (pha, out)
+    return out
+
+
 def fft_cols_fcaffn(z, amp, pha, wxa, wxp):
     B, C, H, Wf, _ = z.shape
-    check(lib().fdn_fft_cols_fcaffn(_flat(z, "z"), _flat(amp, "amp"), _flat(pha, "pha"), _flat(wxa, "wxa"),
-                                    _flat(wxp, "wxp"), B, C, H, Wf, stream()), "fdn_fft_cols_fcaffn")
+    guide = pack_guidance(amp, pha)
+    check(lib().fdn_fft_cols_fcaffn(_flat(z, "z"), _flat(guide, "guide"), _flat(wxa, "wxa"), _flat(wxp, "wxp"), B, C, H, Wf,
+                                    stream()), "fdn_fft_cols_fcaffn")
     return z
 
 

@@ -135,11 +135,15 @@ int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t 
  * out = scale * c2r(in) + alpha * res  (res may be NULL).  Im of bins 0 and W/2 is ignored. */
 int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane_bins, float* out, long planes, int H, int W,
                    float scale, const float* res, float alpha, fdn_stream_t stream);
+/* Interleave the FCAFFN guidance (x_high = amplitude, xp2 = phase, FDN_arch.py:413-414; both [B][3][H][Wf]) into
+ * one 32-byte record per bin: packed [B][H][Wf][8] = (amp0, amp1, amp2, pha0, pha1, pha2, 0, 0).  Done once per
+ * level and forward; every encoder block of the level reads it (a column tile's rows become contiguous). */
+int fdn_pack_guidance(const float* amp, const float* pha, float* packed, int B, int H, int Wf, fdn_stream_t stream);
 /* FCAFFN spectral core, in place on z [B*C][H][Wf] (already row-transformed): column FFT ->
  * replace_denormals -> * conv1_xa(amp) * exp(-i conv1_xp(pha)) -> column iFFT (FDN_arch.py:411-418,
- * SURVEY App. C).  amp,pha [B][3][H][Wf]; wxa,wxp [C][3].  Unscaled (scale in fdn_irfft_rows). */
-int fdn_fft_cols_fcaffn(float* z, const float* amp, const float* pha, const float* wxa, const float* wxp, int B, int C,
-                        int H, int Wf, fdn_stream_t stream);
+ * SURVEY App. C).  guide = fdn_pack_guidance output; wxa,wxp [C][3].  Unscaled (scale in fdn_irfft_rows). */
+int fdn_fft_cols_fcaffn(float* z, const float* guide, const float* wxa, const float* wxp, int B, int C, int H, int Wf,
+                        fdn_stream_t stream);
 /* Forward column FFT of z [planes][H][Wf] -> |z| and/or angle(z) as real planes (FDN_arch.py:91-92,
  * :140-141, :883-884, :904).  rd_before: replace_denormals first; fix_real: force Im=+0 at the four
  * self-conjugate bins of a real input (what a real-FFT library returns; keeps angle=+pi there). */
