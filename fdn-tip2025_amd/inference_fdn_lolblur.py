@@ -1,0 +1,89 @@
+"""LOL-Blur inference driver on the HIP path: the role of the reference's inference_fdn_lolblur.py:1-75
+(load LPNet + FDN checkpoints, walk a directory of low-light blurry frames, write the enhanced frames), with
+the paths as arguments instead of constants and the per-image host work moved to the GPU:
+
+    decode (PIL, worker threads)  ->  uint8 HWC on the GPU  ->  fdn_pre_u8  ->  LPNet -> FDN  ->  fdn_post_u8  ->  encode
+
+Images of equal size are batched (the reference runs batch 1; every op of the path is per-sample).
+Needs a ROCm GPU and the built libfdn_hip.so; there is no CPU fallback.
+
+    python inference_fdn_lolblur.py --fdn FDN_lolblur.pth --lpnet LPNet_lolblur.pth --input 'frames/*.png' --output out/
+"""
+import argparse
+import glob
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def read_rgb(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+
+
+def write_rgb(path, arr):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    Image.fromarray(arr, mode="RGB").save(path)
+
+
+def load_params(path):
+    sd = torch.load(path, map_location="cpu")
+    return sd["params"] if isinstance(sd, dict) and "params" in sd else sd     # inference_fdn_lolblur.py:28,31
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--fdn", required=True, help="FDN checkpoint ({'params': state_dict}, 1503 keys)")
+    ap.add_argument("--lpnet", required=True, help="LPNet checkpoint (292 keys)")
+    ap.add_argument("--input", required=True, help="glob of input frames")
+    ap.add_argument("--output", required=True, help="output directory")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--device", default="cuda:0")
+    a = ap.parse_args()
+
+    from basicsr.models.archs.FDN_arch import FDN
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from fdn_hip.harness import enhance_u8
+
+    dev = torch.device(a.device)
+    torch.cuda.set_device(dev)
+    net = FDN().to(dev).eval()
+    net.load_state_dict(load_params(a.fdn), strict=True)
+    lp = I_predict_net().to(dev).eval()
+    lp.load_state_dict(load_params(a.lpnet), strict=True)
+
+    paths = sorted(glob.glob(a.input))
+    if not paths:
+        raise SystemExit(f"no input frames match {a.input}")
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        decoded = pool.map(read_rgb, paths)                               # decode runs ahead of the GPU
+        pending, writers = [], []
+
+        def flush():
+            if not pending:
+                return
+            batch = torch.from_numpy(np.stack([im for _, im in pending])).to(dev, non_blocking=True)
+            out = enhance_u8(net, lp, batch, bgr=False).cpu().numpy()
+            for (p, _), o in zip(pending, out):
+                writers.append(pool.submit(write_rgb, os.path.join(a.output, os.path.basename(p)), o))
+            pending.clear()
+
+        for p, im in zip(paths, decoded):
+            if pending and (pending[0][1].shape != im.shape or len(pending) == a.batch):
+                flush()
+            pending.append((p, im))
+        flush()
+        for w in writers:
+            w.result()
+    print(f"{len(paths)} frames -> {a.output}")
+
+
+if __name__ == "__main__":
+    main()

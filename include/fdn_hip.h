@@ -182,6 +182,16 @@ int fdn_se_apply(const float* y, const float* gate, const float* shortcut, float
 int fdn_scale_batch(float* x, const float* ratio, int B, long per_batch, fdn_stream_t stream);
 int fdn_gamma_curve(const float* x, const float* i_map, float* out, float scale, long total, fdn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The step either side of the path, batched.
+ * fdn_pre_u8: uint8 HWC images [B][h][w][3] -> fp32 /255 -> CHW -> reflect-pad bottom/right to [B][3][H][W]
+ *   (inference_fdn_lolblur.py:47-62, basicsr/utils/img_util.py:9-33).  swap_rb = 1 for BGR input (cv2.imread),
+ *   0 when the buffer is already RGB.
+ * fdn_post_u8: [B][3][H][W] fp32 -> crop [:h,:w] -> clamp(0,1) -> *255 -> round half-to-even -> uint8 HWC
+ *   [B][h][w][3] (inference_fdn_lolblur.py:72-75, basicsr/utils/img_util.py:36-98); swap_rb = 1 writes BGR. */
+int fdn_pre_u8(const unsigned char* img, float* out, int B, int h, int w, int H, int W, int swap_rb, fdn_stream_t stream);
+int fdn_post_u8(const float* res, unsigned char* out, int B, int h, int w, int H, int W, int swap_rb, fdn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

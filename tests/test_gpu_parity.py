@@ -173,6 +173,41 @@ def test_harness_u8(A):
     assert abs(diff).max() <= 1 and (diff != 0).mean() < 5e-3
 
 
+def test_harness_pre_post_kernels_bit_exact(A):
+    """fdn_pre_u8 / fdn_post_u8 against the oracle's host restatement (inference_fdn_lolblur.py:47-62,72-75): byte and
+    float work, so bit-exact; batch of two, odd sizes, values on the .5 rounding boundary and outside [0,1]."""
+    from fdn_hip import harness
+    g = torch.Generator().manual_seed(5)
+    for (h, w) in ((70, 90), (33, 64), (64, 64)):
+        imgs = torch.randint(0, 256, (2, h, w, 3), generator=g, dtype=torch.uint8)
+        x, hh, ww = harness.preprocess(imgs.cuda(), bgr=True)
+        assert (hh, ww) == (h, w) and x.shape[-2] % 32 == 0 and x.shape[-1] % 32 == 0
+        for b in range(2):
+            ref, _, _ = O.harness_pre(imgs[b].numpy())
+            assert torch.equal(x[b:b + 1].cpu(), ref)
+        res = torch.randn(2, 3, x.shape[-2], x.shape[-1], generator=g) * 0.6 + 0.5
+        res[0, :, 0, :8] = torch.tensor([0.5, 1.5, 2.5, 3.5, 126.5, 127.5, 254.5, 255.0]) / 255.0   # ties -> even
+        out = harness.postprocess(res.cuda(), h, w, bgr=True).cpu().numpy()
+        for b in range(2):
+            assert (out[b] == O.harness_post(res[b:b + 1], h, w)).all()
+        rgb = harness.postprocess(res.cuda(), h, w, bgr=False).cpu().numpy()
+        assert (rgb[..., ::-1] == out).all()
+
+
+def test_harness_enhance_u8_matches_fixture(A):
+    """uint8 in -> uint8 out entirely on the GPU (fdn_hip.harness.enhance_u8) against the reference-generated fixture."""
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from fdn_hip import harness
+    fx = fixture("harness_u8")
+    net = load(A.FDN(), fdn_weights(tame=float(fx["tame"])))
+    lp = load(I_predict_net(), lpnet_weights())
+    img = fx["img"].cuda().contiguous()
+    out = harness.enhance_u8(net, lp, torch.stack([img, img]), bgr=True).cpu().numpy()
+    assert (out[0] == out[1]).all()
+    diff = out[0].astype(int) - fx["out_u8"].numpy().astype(int)
+    assert abs(diff).max() <= 1 and (diff != 0).mean() < 5e-3
+
+
 def test_batch_independence_and_determinism(A):
     """Samples never mix: out(batch)[i] == out(sample i), bit for bit; reruns identical."""
     m = load(A.FDN(), fdn_weights(tame=0.03))

@@ -80,3 +80,15 @@ def test_product_path_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".sh")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "fdn_oracle" not in txt and "oracle/" not in txt, os.path.join(dp, f)
+
+
+def test_harness_rejects_cpu_tensors():
+    """The GPU pre/post stage has no host fallback either: CPU tensors are refused before any library call."""
+    import torch
+    import fdn_hip
+    from fdn_hip import harness
+    assert harness.padded_size(720, 1280) == (736, 1280) and harness.padded_size(64, 96) == (64, 96)
+    with pytest.raises(fdn_hip.FdnHipError):
+        harness.preprocess(torch.zeros(1, 40, 40, 3, dtype=torch.uint8))
+    with pytest.raises(fdn_hip.FdnHipError):
+        harness.postprocess(torch.zeros(1, 3, 64, 64), 40, 40)
