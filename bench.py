@@ -34,14 +34,19 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_F32_MFMA_TF = 157.3          # MI355X_MICROARCH.md: fp32 MFMA dense peak
 
 
-def build_models(dev):
-    from basicsr.models.archs.FDN_arch import FDN
+def build_models(dev, variant="lolblur"):
     from basicsr.models.archs.LPNet_arch import I_predict_net
     from weights import shapes_of, synth_state_dict
-    net = FDN().eval()
-    net.load_state_dict(synth_state_dict(shapes_of(net), seed=7, prefix_key="fdn/", tame=0.03), strict=True)
+    if variant == "lolv1":                                       # dim-24 model, not the headline config
+        from basicsr.models.archs.fdnlol24_arch import FDN_lolv1
+        net = FDN_lolv1().eval()
+        net.load_state_dict(synth_state_dict(shapes_of(net), seed=7, prefix_key="fdnlol/", tame=0.03), strict=True)
+    else:
+        from basicsr.models.archs.FDN_arch import FDN
+        net = FDN().eval()
+        net.load_state_dict(synth_state_dict(shapes_of(net), seed=7, prefix_key="fdn/", tame=0.03), strict=True)
     lp = I_predict_net().eval()
-    gold = os.path.join(ROOT, "tests", "golden", "lpnet_lolblur_params.npz")
+    gold = os.path.join(ROOT, "tests", "golden", f"lpnet_{variant}_params.npz")
     if os.path.isfile(gold):
         import numpy as np
         z = np.load(gold)
@@ -171,6 +176,8 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the per-GPU batch is split over")
     ap.add_argument("--scatter-gather", action="store_true", help="time RCCL scatter of inputs / gather of outputs too")
+    ap.add_argument("--variant", choices=("lolblur", "lolv1"), default="lolblur",
+                    help="lolblur = FDN (BASELINE.json's metric); lolv1 = FDN_lolv1, dim 24 (SURVEY.md 8(f) rank 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -189,7 +196,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
 
     from fdn_hip.pipeline import forward_streams
-    net, lp = build_models(dev)
+    net, lp = build_models(dev, a.variant)
     x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
     B, _, H, W = x.shape
     root_in = root_out = None
@@ -258,11 +265,13 @@ def main():
         ips = imgs / dt
         P = H * W
         line = {
-            "metric": "images/sec, FDN (LPNet->FDN forward) 1280x720 bs=8 fp32",
+            "metric": ("images/sec, FDN (LPNet->FDN forward) 1280x720 bs=8 fp32" if a.variant == "lolblur" else
+                       f"images/sec, FDN_lolv1 (LPNet->FDN_lolv1 forward) {a.width}x{a.height} bs={B} fp32 [not the headline metric]"),
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "ms_per_image": 1e3 / ips * world, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: FDN {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU fp32",
+            "config": {"workload": (f"BASELINE.json configs[1]: FDN {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU fp32" if a.variant == "lolblur"
+                                    else f"FDN_lolv1 (dim 24) {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU fp32"),
                        "global_batch": world * B, "parallelism": f"batch-shard x{world}", "weights": "synthetic (tamed 0.03) FDN + real LPNet",
                        "scatter_gather_timed": bool(a.scatter_gather), "hip_streams": a.streams},
             "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * 4.0 * P * (ips / world) / (PEAK_HBM_GBS * 1e9),

@@ -387,18 +387,24 @@ class fourier_fuse(nn.Module):
 
 
 class MAR_archa(nn.Module):
-    def __init__(self, use_ratio=True):
+    def __init__(self, use_ratio=True, block=None, apply_ratio=True):
+        """block: the ProcessBlock class (the LOL-v1 variant, fdnlol24_arch.py, has a live `.cat` conv).
+        apply_ratio: the reference multiplies by `ratio` unconditionally here (FDN_arch.py:213-219, `use_ratio`
+        is ignored) and conditionally in the LOL-v1 file (fdnlol24_arch.py:160-169)."""
         super().__init__()
+        ProcessBlock_ = ProcessBlock if block is None else block
+        self.use_ratio = use_ratio
+        self.apply_ratio = apply_ratio
         c = 12
-        self.Encoder = nn.ModuleList([ProcessBlock(c), ProcessBlock(c * 2), ProcessBlock(c * 4)])
-        self.Decoder = nn.ModuleList([ProcessBlock(c * 4), ProcessBlock(c * 2), ProcessBlock(c)])
+        self.Encoder = nn.ModuleList([ProcessBlock_(c), ProcessBlock_(c * 2), ProcessBlock_(c * 4)])
+        self.Decoder = nn.ModuleList([ProcessBlock_(c * 4), ProcessBlock_(c * 2), ProcessBlock_(c)])
         self.Convs = nn.ModuleList([BasicConv(c * 4, c * 2, 1, 1, relu=True), BasicConv(c * 2, c, 1, 1, relu=True)])
         self.ConvsOut = nn.ModuleList([BasicConv(c * 4, 3, 3, 1, relu=False), BasicConv(c * 2, 3, 3, 1, relu=False)])
         self.AFFs = nn.ModuleList([fourier_fuse(c * 7, c), fourier_fuse(c * 7, c * 2)])
         self.FAM1 = FAM(c * 4)
-        self.f1 = nn.Sequential(nn.Conv2d(3 * 16, c * 4, 1, 1, 0), ProcessBlock(c * 4))
-        self.f2 = nn.Sequential(nn.Conv2d(3 * 4, c * 2, 1, 1, 0), ProcessBlock(c * 2))
-        self.f3 = nn.Sequential(nn.Conv2d(3, c, 1, 1, 0), ProcessBlock(c))
+        self.f1 = nn.Sequential(nn.Conv2d(3 * 16, c * 4, 1, 1, 0), ProcessBlock_(c * 4))
+        self.f2 = nn.Sequential(nn.Conv2d(3 * 4, c * 2, 1, 1, 0), ProcessBlock_(c * 2))
+        self.f3 = nn.Sequential(nn.Conv2d(3, c, 1, 1, 0), ProcessBlock_(c))
         self.f3_down = BasicConv(c, c * 2, 3, 2, relu=True)
         self.f2_down = BasicConv(c * 2, c * 4, 3, 2, relu=True)
         self.f2_up = BasicConv(c * 4, c * 2, 4, 2, relu=True, transpose=True)
@@ -406,10 +412,9 @@ class MAR_archa(nn.Module):
         self.out = BasicConv(c, 3, 3, 1, relu=False)
         self.FAM2 = FAM(c * 2)
 
-    @staticmethod
-    def _stem(seq, x, ratio):
-        t = ops.conv1x1(x, _w(seq[0].weight), _w(seq[0].bias))
-        return ops.scale_batch_(seq[1](t), ratio)
+    def _stem(self, seq, x, ratio):
+        t = seq[1](ops.conv1x1(x, _w(seq[0].weight), _w(seq[0].bias)))
+        return ops.scale_batch_(t, ratio) if self.apply_ratio else t
 
     def forward(self, x, ratio):
         """ratio: flat [B] tensor; always applied (FDN_arch.py:213-219)."""

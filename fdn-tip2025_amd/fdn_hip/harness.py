@@ -57,10 +57,26 @@ def postprocess(result, h, w, bgr=True):
     return out
 
 
+def lolv1_ratio(x, lp_ratio):
+    """inference_fdn_lolv1.py:57-61: ratio_i = mean(Grayscale(padded input)) / LPNet(padded input).  The plane means
+    come from fdn_global_avgpool; Grayscale is linear (0.2989 R + 0.587 G + 0.114 B), so its mean is the same
+    combination of the three plane means ([B,3] values, combined on the device)."""
+    from . import ops
+    m = ops.global_avgpool(x).reshape(x.shape[0], 3)
+    gray = 0.2989 * m[:, 0:1] + 0.587 * m[:, 1:2] + 0.114 * m[:, 2:3]
+    return gray / lp_ratio
+
+
 @torch.no_grad()
-def enhance_u8(net, lpnet, img_u8, bgr=True):
-    """uint8 in -> uint8 out through LPNet -> FDN (the body of the reference's per-image loop, batched)."""
+def enhance_u8(net, lpnet, img_u8, bgr=True, ratio_mode="lolblur"):
+    """uint8 in -> uint8 out through LPNet -> FDN (the body of the reference's per-image loop, batched).
+    ratio_mode: "lolblur" feeds LPNet's prediction (inference_fdn_lolblur.py:69-71), "lolv1" feeds
+    mean(gray)/prediction (inference_fdn_lolv1.py:57-62)."""
+    if ratio_mode not in ("lolblur", "lolv1"):
+        raise ValueError(f"ratio_mode {ratio_mode!r}")
     x, h, w = preprocess(img_u8, bgr=bgr)
     ratio = lpnet(x)
+    if ratio_mode == "lolv1":
+        ratio = lolv1_ratio(x, ratio)
     result = net(x, ratio_i=ratio, device=x.device)[0]
     return postprocess(result.contiguous(), h, w, bgr=bgr)

@@ -213,8 +213,11 @@ def freblock(x, P, pfx):
     return torch.fft.irfft2(z, s=(H, W)) + x
 
 
-def processblock(x, P, pfx):
-    """ProcessBlock(spatial=False).forward, FDN_arch.py:109-118: FreBlock(x)+x; `.cat` is dead."""
+def processblock(x, P, pfx, cat=False):
+    """ProcessBlock(spatial=False).forward.  FDN_arch.py:109-118: FreBlock(x)+x, `.cat` is dead.
+    cat=True is the LOL-v1 variant, fdnlol24_arch.py:769-776: cat(FreBlock(x)) + x (a live 1x1 conv)."""
+    if cat:
+        return _conv(freblock(x, P, pfx + ".frequency_process"), P, pfx + ".cat") + x
     return freblock(x, P, pfx + ".frequency_process") + x
 
 
@@ -242,8 +245,11 @@ def _basic_t(x, P, pfx):
     return F.leaky_relu(y, 0.1)
 
 
-def mar_arch(x, ratio, P, pfx):
-    """MAR_archa.forward, FDN_arch.py:203-257.  ratio: (B,1,1,1); always applied (:213-219)."""
+def mar_arch(x, ratio, P, pfx, cat=False):
+    """MAR_archa.forward, FDN_arch.py:203-257.  ratio: (B,1,1,1); always applied (:213-219).
+    cat=True: fourier_multi_scale_gamma2 of the LOL-v1 variant (fdnlol24_arch.py:147-209; use_ratio=True there,
+    :991), identical wiring with the live `.cat` ProcessBlock."""
+    processblock = lambda t, P_, pf: globals()["processblock"](t, P_, pf, cat)
     x_2 = x[:, :, ::2, ::2]                       # nearest 0.5, :205
     x_4 = x_2[:, :, ::2, ::2]                     # :206
     z2 = processblock(_conv(F.pixel_unshuffle(x, 2), P, pfx + ".f2.0"), P, pfx + ".f2.1") * ratio
@@ -275,12 +281,12 @@ def mar_arch(x, ratio, P, pfx):
     return o4, o2, o1
 
 
-def mar(x, ratio, P, pfx="net_a"):
+def mar(x, ratio, P, pfx="net_a", cat=False):
     """MAR.forward, FDN_arch.py:269-286: gamma curve 1-(1-x_k)^(40*i_k) on a bilinear pyramid."""
     x1 = x
     x2 = bilinear_half(x1)
     x3 = bilinear_half(x2)
-    i3, i2, i1 = mar_arch(x, ratio, P, pfx + ".net")
+    i3, i2, i1 = mar_arch(x, ratio, P, pfx + ".net", cat)
     g = lambda xx, ii: 1.0 - torch.pow(1.0 - xx, ii * 40.0)
     return g(x3, i3), g(x2, i2), g(x1, i1)
 
@@ -288,7 +294,7 @@ def mar(x, ratio, P, pfx="net_a"):
 # --------------------------------------------------------------------------------------
 # FDN top level
 # --------------------------------------------------------------------------------------
-def fdn_guidance(inp, ratio_i, P):
+def fdn_guidance(inp, ratio_i, P, cat=False):
     """FDN.forward up to the FDformer call, FDN_arch.py:869-914.
     Returns (amps, phas, imgs) for levels 1..3 and the three MAR outputs."""
     r = ratio_i.view(-1, 1, 1, 1)                                                # :872
@@ -298,7 +304,7 @@ def fdn_guidance(inp, ratio_i, P):
     pyr = [p1, p2, p3]
     norms = ["norm1", "norm2", "norm3"]
     phas = [replace_denormals(torch.fft.rfft2(_ln(pyr[i], P, norms[i]))).angle() for i in range(3)]  # :878-892
-    q3, q2, q1 = mar(inp, r, P, "net_a")                                         # :895
+    q3, q2, q1 = mar(inp, r, P, "net_a", cat)                                    # :895
     imgs = [q1, q2, q3]
     amps = [torch.fft.rfft2(_ln(imgs[i], P, norms[i])).abs() for i in range(3)]  # :896-914
     return amps, phas, imgs
@@ -310,6 +316,22 @@ def fdn_forward(P, inp, ratio_i):
     amps, phas, imgs = fdn_guidance(inp, ratio_i, P)
     out = fdformer(inp, inp, amps, phas, imgs, P, "net_p")                       # :916-919
     return out, imgs[0], imgs[1], imgs[2]
+
+
+def fdn_lolv1_forward(P, inp, ratio_i):
+    """FDN_lolv1.forward, fdnlol24_arch.py:982-1033: the same graph at dim=24 (E = 28/57/115, Hd = 64/129/259;
+    widths come from the weights), MAR with the live ProcessBlock.cat, and the result returned four times."""
+    amps, phas, imgs = fdn_guidance(inp, ratio_i, P, cat=True)
+    out = fdformer(inp, inp, amps, phas, imgs, P, "net_p")
+    return out, out, out, out
+
+
+def lolv1_ratio(padded, lp_ratio):
+    """inference_fdn_lolv1.py:57-61: mean over pixels of Grayscale(padded input) divided by LPNet's prediction.
+    Grayscale = 0.2989 R + 0.587 G + 0.114 B (torchvision.transforms.functional.rgb_to_grayscale)."""
+    r, g, b = padded.unbind(dim=1)
+    gray = (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(1)
+    return gray.mean(dim=(2, 3)) / lp_ratio
 
 
 # --------------------------------------------------------------------------------------

@@ -45,9 +45,24 @@ def fdn_weights(tame=0.03):
     return synth_state_dict(fdn_shapes(), SEED, prefix_key="fdn/", tame=tame)
 
 
-def lpnet_weights():
-    z = np.load(os.path.join(GOLDEN, "lpnet_lolblur_params.npz"))
+def lpnet_weights(which="lolblur"):
+    z = np.load(os.path.join(GOLDEN, f"lpnet_{which}_params.npz"))
     return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+_lolv1_shapes = None
+
+
+def lolv1_shapes():
+    global _lolv1_shapes
+    if _lolv1_shapes is None:
+        _lolv1_shapes = fixture("lolv1_tamed_64")["shapes"]
+    return _lolv1_shapes
+
+
+def lolv1_weights(tame=0.03):
+    """FDN_lolv1 (dim 24) synthetic state dict, the one tests/golden/make_golden_lolv1.py loaded into the reference."""
+    return synth_state_dict(lolv1_shapes(), SEED, prefix_key="fdnlol/", tame=tame)
 
 
 def rel_rms(a, b):

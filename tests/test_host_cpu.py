@@ -92,3 +92,15 @@ def test_harness_rejects_cpu_tensors():
         harness.preprocess(torch.zeros(1, 40, 40, 3, dtype=torch.uint8))
     with pytest.raises(fdn_hip.FdnHipError):
         harness.postprocess(torch.zeros(1, 3, 64, 64), 40, 40)
+
+
+def test_lolv1_state_dict_layout_matches_reference():
+    """FDN_lolv1 (dim 24): same 1503 keys / shapes as the reference module, so its checkpoint loads strict."""
+    from basicsr.models.archs.fdnlol24_arch import FDN_lolv1
+    from common import lolv1_shapes, lolv1_weights
+    net = FDN_lolv1()
+    sd, ref = net.state_dict(), lolv1_shapes()
+    assert len(sd) == 1503 and set(sd) == set(ref)
+    assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    assert sd["net_p.patch_embed.proj.weight"].shape[0] == 24 and "net_a.net.Encoder.0.cat.weight" in sd
+    net.load_state_dict(lolv1_weights(), strict=True)
