@@ -239,10 +239,13 @@ def main():
 
     roof = None
     if rank == 0 and not a.no_roofline:
-        with KernelTimer() as kt:
-            with torch.no_grad():
-                net(x, ratio_i=lp(x), device=dev)                   # single stream: events bracket each launch
-        agg = kt.summary()
+        agg = None
+        for _ in range(2):                                          # the first instrumented pass also pays one-off host costs
+            with KernelTimer() as kt:
+                with torch.no_grad():
+                    net(x, ratio_i=lp(x), device=dev)               # single stream: events bracket each launch
+            cur = kt.summary()
+            agg = cur if agg is None else {k: (v if v[1] <= agg.get(k, v)[1] else agg[k]) for k, v in cur.items()}
         total_ms = sum(v[1] for v in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         name, (cnt, ms, fl, by) = dom

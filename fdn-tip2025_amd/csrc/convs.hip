@@ -67,47 +67,128 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
     }
 }
 
-// ConvTranspose2d(Cin, Cout, 4, stride 2, padding 1): weight [Cin][Cout][4][4]; OH = 2H, OW = 2W
-__global__ __launch_bounds__(256) void convT_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, float* __restrict__ out, int Cin, int H,
-                                                    int W, int Cout, int act) {
-    const int OH = 2 * H, OW = 2 * W;
+// 3x3 / pad 1 / stride S specialisation for the narrow convs (Cout < 8 or stride 2; the wide stride-1 ones go
+// to the MFMA kernel): the OCB-channel weight slice sits in LDS as [Cin][9][OCB] (one broadcast b128 read
+// per 4 channels), the nine tap offsets and their validity are computed once per thread, and the nine loads
+// of an input channel are issued together - the generic kernel above pays one global + OCB scalar round trips
+// per tap.
+template <int S, int OCB_>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int oc0 = blockIdx.y * OCB_, b = blockIdx.z;
+    const int nvalid = min(OCB_, a.Cout - oc0);
+    for (int i = threadIdx.x; i < a.Cin * 9 * OCB_; i += 256) {
+        const int o = i % OCB_, t = (i / OCB_) % 9, ci = i / (OCB_ * 9);
+        wl[i] = o < nvalid ? a.w[((long)(oc0 + o) * a.Cin + ci) * 9 + t] : 0.f;
+    }
+    __syncthreads();
     const long op = (long)blockIdx.x * 256 + threadIdx.x;
-    const int oc0 = blockIdx.y * OCB, b = blockIdx.z;
-    const long OP = (long)OH * OW;
+    const long OP = (long)a.OH * a.OW;
     const bool live = op < OP;
-    const int oy = live ? (int)(op / OW) : 0, ox = live ? (int)(op - (long)oy * OW) : 0;
-    const int nvalid = min(OCB, Cout - oc0);
-    float acc[OCB];
+    const int oy = live ? (int)(op / a.OW) : 0, ox = live ? (int)(op - (long)oy * a.OW) : 0;
+    int off[9];
+    unsigned ok = 0;
 #pragma unroll
-    for (int o = 0; o < OCB; ++o) acc[o] = 0.f;
-    const long hw = (long)H * W;
-    // stride 2, pad 1, k 4: output row oy takes input rows iy with 2*iy = oy + 1 - ky, i.e. the two
-    // taps ky = (oy+1)&1 and ky + 2 (same for columns): 4 of the 16 taps are live per output pixel
-    const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float* xc = x + ((long)b * Cin + ci) * hw;
+    for (int t = 0; t < 9; ++t) {
+        const int iy = oy * S - 1 + t / 3, ix = ox * S - 1 + t % 3;
+        const bool v = live && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        off[t] = v ? iy * a.W + ix : 0;
+        ok |= (v ? 1u : 0u) << t;
+    }
+    float acc[OCB_];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int ky = ky0 + 2 * a;
-            const int iy = (oy + 1 - ky) >> 1;
-            const bool yok = (oy + 1 - ky) >= 0 && iy < H;
+    for (int o = 0; o < OCB_; ++o) acc[o] = 0.f;
+    const long hw = (long)a.H * a.W;
+    const float* xc = a.x + (long)b * a.Cin * hw;
+    for (int ci = 0; ci < a.Cin; ++ci, xc += hw) {
+        float v[9];
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const int kx = kx0 + 2 * c2;
-                const int ix = (ox + 1 - kx) >> 1;
-                const bool ok = live && yok && (ox + 1 - kx) >= 0 && ix < W;
-                const float v = ok ? xc[(long)iy * W + ix] : 0.f;
-                const float* wp = w + ((long)ci * Cout + oc0) * 16 + ky * 4 + kx;
+        for (int t = 0; t < 9; ++t) v[t] = xc[off[t]];
 #pragma unroll
-                for (int o = 0; o < OCB; ++o)
-                    if (o < nvalid) acc[o] = fmaf(v, wp[o * 16], acc[o]);
-            }
+        for (int t = 0; t < 9; ++t) {
+            const float vv = ((ok >> t) & 1u) ? v[t] : 0.f;
+            const float* wp = wl + (ci * 9 + t) * OCB_;
+#pragma unroll
+            for (int o = 0; o < OCB_; ++o) acc[o] = fmaf(vv, wp[o], acc[o]);
         }
     }
     if (!live) return;
 #pragma unroll
-    for (int o = 0; o < OCB; ++o) {
+    for (int o = 0; o < OCB_; ++o) {
+        if (o >= nvalid) break;
+        const int oc = oc0 + o;
+        float v = acc[o] + (a.bias ? a.bias[oc] : 0.f);
+        const long oi = ((long)b * a.Cout + oc) * OP + op;
+        if (a.res && a.res_before_act) v += a.res[oi];
+        v = apply_act(v, a.act);
+        if (a.res && !a.res_before_act) v += a.res[oi];
+        a.out[oi] = v + a.post_add;
+    }
+}
+
+template <int S, int OCB_>
+int launch_conv3x3_direct(const ConvArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)a.Cin * 9 * OCB_ * sizeof(float);
+    if (lds > 64 * 1024) return FDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv3x3_direct_kernel<S, OCB_>), dim3(cdiv((long)a.OH * a.OW, 256), cdiv(a.Cout, OCB_), a.B), dim3(256),
+                       lds, s, a);
+    return fdn_launch_status();
+}
+
+// ConvTranspose2d(Cin, Cout, 4, stride 2, padding 1): weight [Cin][Cout][4][4]; OH = 2H, OW = 2W.
+// stride 2, pad 1, k 4: output row oy takes input rows iy with 2*iy = oy + 1 - ky, i.e. the two taps
+// ky = (oy+1)&1 and ky + 2 (same for columns): 4 of the 16 taps are live per output pixel.  The OCB-channel
+// weight slice sits in LDS as [Cin][16][OCB]; the four loads of an input channel are issued together.
+template <int OCB_>
+__global__ __launch_bounds__(256) void convT_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int Cin, int H,
+                                                    int W, int Cout, int act) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int oc0 = blockIdx.y * OCB_, b = blockIdx.z;
+    const int nvalid = min(OCB_, Cout - oc0);
+    for (int i = threadIdx.x; i < Cin * 16 * OCB_; i += 256) {
+        const int o = i % OCB_, t = (i / OCB_) % 16, ci = i / (OCB_ * 16);
+        wl[i] = o < nvalid ? w[((long)ci * Cout + oc0 + o) * 16 + t] : 0.f;
+    }
+    __syncthreads();
+    const int OH = 2 * H, OW = 2 * W;
+    const long op = (long)blockIdx.x * 256 + threadIdx.x;
+    const long OP = (long)OH * OW;
+    const bool live = op < OP;
+    const int oy = live ? (int)(op / OW) : 0, ox = live ? (int)(op - (long)oy * OW) : 0;
+    const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
+    int off[4], tap[4];
+    unsigned ok = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ky = ky0 + 2 * (j >> 1), kx = kx0 + 2 * (j & 1);
+        const int ny = oy + 1 - ky, nx = ox + 1 - kx;
+        const int iy = ny >> 1, ix = nx >> 1;
+        const bool v = live && ny >= 0 && iy < H && nx >= 0 && ix < W;
+        off[j] = v ? iy * W + ix : 0;
+        tap[j] = (ky * 4 + kx) * OCB_;
+        ok |= (v ? 1u : 0u) << j;
+    }
+    float acc[OCB_];
+#pragma unroll
+    for (int o = 0; o < OCB_; ++o) acc[o] = 0.f;
+    const long hw = (long)H * W;
+    const float* xc = x + (long)b * Cin * hw;
+    for (int ci = 0; ci < Cin; ++ci, xc += hw) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = xc[off[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float vv = ((ok >> j) & 1u) ? v[j] : 0.f;
+            const float* wp = wl + ci * 16 * OCB_ + tap[j];
+#pragma unroll
+            for (int o = 0; o < OCB_; ++o) acc[o] = fmaf(vv, wp[o], acc[o]);
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int o = 0; o < OCB_; ++o) {
         if (o >= nvalid) break;
         out[((long)b * Cout + oc0 + o) * OP + op] = apply_act(acc[o] + (bias ? bias[oc0 + o] : 0.f), act);
     }
@@ -224,11 +305,6 @@ extern "C" int fdn_conv2d(const float* x, const float* w, const float* bias, con
                           int H, int W, int Cout, int KH, int KW, int stride, int pad, int act, int res_before_act,
                           float post_add, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1) {
-        const int rc = fdn_conv3x3_mfma(x, w, bias, res, out, B, Cin, H, W, Cout, act, res_before_act, post_add,
-                                        static_cast<hipStream_t>(stream));
-        if (rc != FDN_ERR_UNSUPPORTED) return rc;
-    }
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.res = res; a.out = out;
     a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
@@ -236,16 +312,38 @@ extern "C" int fdn_conv2d(const float* x, const float* w, const float* bias, con
     a.OW = (W + 2 * pad - KW) / stride + 1;
     FDN_CHECK_ARG(a.OH > 0 && a.OW > 0);
     a.act = act; a.res_before_act = res_before_act; a.post_add = post_add;
-    hipLaunchKernelGGL(conv2d_kernel, dim3(cdiv((long)a.OH * a.OW, 256), cdiv(Cout, OCB), B), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), a);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (KH == 3 && KW == 3 && pad == 1 && (stride == 1 || stride == 2)) {
+        // measured at B=8 720p (tools/gpu_conv_shapes.py): the LDS-weight direct kernel beats the MFMA implicit GEMM
+        // up to 64 output channels (64->32 @L1 5.5 vs 8.4 ms, 12->12 0.47 vs 2.0 ms); wider ones (64->128,
+        // 128->64, whose weight slice does not fit LDS either) stay on MFMA
+        int rc = FDN_ERR_UNSUPPORTED;
+        if (stride == 2) rc = Cout <= 8 ? launch_conv3x3_direct<2, 8>(a, s) : launch_conv3x3_direct<2, 16>(a, s);
+        else if (Cout <= 4) rc = launch_conv3x3_direct<1, 4>(a, s);
+        else if (Cout <= 8) rc = launch_conv3x3_direct<1, 8>(a, s);
+        else if (Cout <= 64) rc = launch_conv3x3_direct<1, 16>(a, s);
+        if (rc != FDN_ERR_UNSUPPORTED) return rc;
+        if (stride == 1) {
+            rc = fdn_conv3x3_mfma(x, w, bias, res, out, B, Cin, H, W, Cout, act, res_before_act, post_add, s);
+            if (rc != FDN_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    hipLaunchKernelGGL(conv2d_kernel, dim3(cdiv((long)a.OH * a.OW, 256), cdiv(Cout, OCB), B), dim3(256), 0, s, a);
     return fdn_launch_status();
 }
 
 extern "C" int fdn_conv_transpose4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H,
                                        int W, int Cout, int act, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
-    hipLaunchKernelGGL(convT_kernel, dim3(cdiv(4L * H * W, 256), cdiv(Cout, OCB), B), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, w, bias, out, Cin, H, W, Cout, act);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cout > 8 && (size_t)Cin * 16 * 16 * sizeof(float) <= 64 * 1024) {
+        hipLaunchKernelGGL(convT_kernel<16>, dim3(cdiv(4L * H * W, 256), cdiv(Cout, 16), B), dim3(256), (size_t)Cin * 16 * 16 * sizeof(float),
+                           s, x, w, bias, out, Cin, H, W, Cout, act);
+    } else {
+        FDN_CHECK_ARG((size_t)Cin * 16 * 8 * sizeof(float) <= 64 * 1024);
+        hipLaunchKernelGGL(convT_kernel<8>, dim3(cdiv(4L * H * W, 256), cdiv(Cout, 8), B), dim3(256), (size_t)Cin * 16 * 8 * sizeof(float), s,
+                           x, w, bias, out, Cin, H, W, Cout, act);
+    }
     return fdn_launch_status();
 }
 

@@ -298,12 +298,23 @@ def test_ffn_tail_fused_equals_reference(A, C, N, H, W):
     assert rel_rms(ops.ffn_tail(yd, wdd, wdv, res=rd).cpu(), ref) < 3e-6         # whichever path the dispatcher picks
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W", [(64, 32, 24, 40), (3, 32, 16, 35), (12, 12, 9, 21), (32, 3, 16, 24), (128, 64, 8, 16)])
-def test_conv3x3_paths(A, Cin, Cout, H, W):
+@pytest.mark.parametrize("Cin,Cout,H,W,stride", [(64, 32, 24, 40, 1), (3, 32, 16, 35, 1), (12, 12, 9, 21, 1), (32, 3, 16, 24, 1),
+                                                 (128, 64, 8, 16, 1), (64, 128, 8, 24, 1), (12, 24, 18, 22, 2), (24, 48, 9, 21, 2),
+                                                 (5, 7, 11, 13, 2)])
+def test_conv3x3_paths(A, Cin, Cout, H, W, stride):
+    """LDS-weight direct kernel (Cout <= 64, stride 1 and 2), MFMA implicit GEMM (wider / slice too big for LDS)."""
     from fdn_hip import ops
     x, w, b = _rnd(2, Cin, H, W, seed=1), _rnd(Cout, Cin, 3, 3, seed=2) / (3 * Cin ** 0.5), _rnd(Cout, seed=3)
-    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
-    assert rel_rms(ops.conv2d(dev(x), dev(w), dev(b), pad=1).cpu(), ref) < 2e-6
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1, stride=stride)
+    assert rel_rms(ops.conv2d(dev(x), dev(w), dev(b), pad=1, stride=stride).cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W", [(24, 12, 9, 13), (48, 24, 8, 16), (6, 5, 7, 9)])
+def test_conv_transpose4x4s2(A, Cin, Cout, H, W):
+    from fdn_hip import ops
+    x, w, b = _rnd(2, Cin, H, W, seed=1), _rnd(Cin, Cout, 4, 4, seed=2) / (4 * Cin ** 0.5), _rnd(Cout, seed=3)
+    ref = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    assert rel_rms(ops.conv_transpose4x4s2(dev(x), dev(w), dev(b), 0).cpu(), ref) < 2e-6
 
 
 def test_fdsa_out_level1_equals_fallback(A):
