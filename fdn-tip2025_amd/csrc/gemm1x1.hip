@@ -48,7 +48,7 @@ __device__ __forceinline__ void bstore(float v, rsrc_t r, unsigned voff, unsigne
 }
 
 template <int MT, int PRO, int NW, bool EARLY>
-__global__ __launch_bounds__(NW * 64) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? 3 : 1) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = NW * 64;
     constexpr int WS = MT * 32 + 1;            // LDS row stride of the transposed weight chunk
@@ -241,25 +241,59 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_kernel(fdn_conv1x1_desc d, Ge
                     const rsrc_t rm = mk_rsrc(d.mul ? d.mul + (long)cur.b * d.mbs : d.out, d.mul ? nb4 : 0u);
                     const rsrc_t rd = mk_rsrc(d.add ? d.add + (long)cur.b * d.mbs : d.out, d.add ? nb4 : 0u);
                     const unsigned voff = (4u * kh * P + cur.pix) * 4u;
+                    // the residual / mul / add operands of one 32-channel tile are requested as a batch before its
+                    // stores: interleaved with the stores hipcc waits for every load separately (it cannot prove res
+                    // and out distinct) - 64 memory round trips per tile at MT = 4, 92k of a tile's 228k cycles
+                    // (tools/gemm_trace.py)
+                    // batch size by register budget: MT = 1 lives on 128 registers (2 workgroups per CU); the wide LN3_GATE
+                    // kernels sit at 256 already and keep the one-by-one form
+                    constexpr int EB = MT == 1 ? 4 : ((PRO == FDN_PRO_LN3_GATE && MT >= 3) ? 1 : 16);
+                    if constexpr (EB == 1) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                        for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int nrow = nbase + m * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh per lane
-                            const unsigned soff = (unsigned)nrow * P4;
-                            float v = acc[m][r];
-                            if (d.bias) { const int n = nrow + 4 * kh; v += (n < N) ? d.bias[n] : 0.f; }
-                            v = apply_act(v, d.act);
-                            if (EARLY) {
-                                if (d.epi == FDN_EPI_RES) v += e0[m * 16 + r];
-                                else if (d.epi == FDN_EPI_MULADD) v = v * e0[m * 16 + r] + e1[m * 16 + r];
-                            } else {
+                            for (int r = 0; r < 16; ++r) {
+                                const int nrow = nbase + m * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh per lane
+                                const unsigned soff = (unsigned)nrow * P4;
+                                float v = acc[m][r];
+                                if (d.bias) { const int n = nrow + 4 * kh; v += (n < N) ? d.bias[n] : 0.f; }
+                                v = apply_act(v, d.act);
                                 if (d.epi == FDN_EPI_RES) v += bload(rr, voff, soff);
                                 else if (d.epi == FDN_EPI_MULADD) v = v * bload(rm, voff, soff) + bload(rd, voff, soff);
+                                bstore(v, ro, voff, soff);
+                                acc[m][r] = (nrow + 4 * kh < N) ? v : 0.f;
                             }
-                            bstore(v, ro, voff, soff);          // rows >= N fall outside the descriptor
-                            acc[m][r] = (nrow + 4 * kh < N) ? v : 0.f;
+                    } else
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                        for (int r0 = 0; r0 < 16; r0 += EB) {
+                            float l0[EB], l1[EB];
+                            if (!EARLY && d.epi != FDN_EPI_NONE) {
+#pragma unroll
+                                for (int j = 0; j < EB; ++j) {
+                                    const int r = r0 + j;
+                                    const unsigned soff = (unsigned)(nbase + m * 32 + (r & 3) + 8 * (r >> 2)) * P4;
+                                    if (d.epi == FDN_EPI_RES) l0[j] = bload(rr, voff, soff);
+                                    else { l0[j] = bload(rm, voff, soff); l1[j] = bload(rd, voff, soff); }
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < EB; ++j) {
+                                const int r = r0 + j;
+                                const int nrow = nbase + m * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kh per lane
+                                const unsigned soff = (unsigned)nrow * P4;
+                                float v = acc[m][r];
+                                if (d.bias) { const int n = nrow + 4 * kh; v += (n < N) ? d.bias[n] : 0.f; }
+                                v = apply_act(v, d.act);
+                                if (d.epi == FDN_EPI_RES) v += EARLY ? e0[m * 16 + r] : l0[j];
+                                else if (d.epi == FDN_EPI_MULADD) v = EARLY ? v * e0[m * 16 + r] + e1[m * 16 + r] : v * l0[j] + l1[j];
+                                bstore(v, ro, voff, soff);          // rows >= N fall outside the descriptor
+                                acc[m][r] = (nrow + 4 * kh < N) ? v : 0.f;
+                            }
+                            if (EB > 1) __builtin_amdgcn_sched_barrier(0);      // keep the next batch from being hoisted up here
                         }
+                    }
                     if (d.stats_out && npass == 1) {
                         // channel LayerNorm statistics of the tile just written (two-pass, registers only):
                         // lane l and l^32 hold complementary rows of the same pixel
@@ -697,6 +731,9 @@ int launch_early(const fdn_conv1x1_desc& d, hipStream_t s) {
     if constexpr (MT <= 2) {
         if (d.epi != FDN_EPI_NONE && d.K <= 64) return launch<MT, PRO, 4, true>(d, s);
     }
+    // measured (tools/gpu_gemm_shapes.py): 64-wide plain GEMMs (FDFFN project_out at level 2, 172 -> 64) gain from
+    // 4-wave workgroups at 3 waves per SIMD (13.5 -> 10.9 ms); wider tiles spill at that register budget
+    if constexpr (MT == 2 && PRO == FDN_PRO_NONE) return launch<MT, PRO, 4, false>(d, s);
     return launch<MT, PRO, 8, false>(d, s);
 }
 

@@ -1,0 +1,30 @@
+"""Per-step s_memtime trace of the generic conv1x1 kernel (needs the -DFDN_GEMM_TRACE build: FDN_HIP_LIB=abtest/libT.so)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+import torch
+import fdn_hip
+from fdn_hip import Conv1x1Desc
+dev = torch.device("cuda:0")
+B, K, N, H, W = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 345, int(sys.argv[2]) if len(sys.argv) > 2 else 128, 184, 320
+P = H * W
+x = torch.randn(B, K, H, W, device=dev); w = torch.randn(N, K, device=dev) / K ** .5
+res = torch.randn(B, N, H, W, device=dev); out = torch.empty_like(res)
+trace = torch.zeros(2048, dtype=torch.int64, device=dev)
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+d = Conv1x1Desc()
+d.x[0] = p(x); d.xbs[0] = K * P; d.kseg[0] = K
+d.w = p(w); d.out = p(out); d.obs = N * P; d.B, d.K, d.N, d.P = B, K, N, P
+d.pro = 0; d.epi = 1; d.res = p(res); d.rbs = N * P; d.act = 0
+d.gamma = p(trace); d.vec4 = 12345
+for _ in range(2):
+    rc = fdn_hip.lib().fdn_conv1x1(ctypes.byref(d), fdn_hip.stream()); assert rc == 0, rc
+torch.cuda.synchronize()
+t = trace.cpu().view(2, 128, 8)
+for wv in (0, 1):
+    print("wave", wv * 4)
+    t0 = int(t[wv, 0, 0])
+    for s in range(0, 40):
+        r = [int(v) for v in t[wv, s, :6]]
+        if r[0] == 0: break
+        print(f" step {s:3d} begin {r[0]-t0:8d}  issue {r[1]-r[0]:6d}  mfma {r[2]-r[1]:6d}  epi {r[3]-r[2]:6d}  stash {r[4]-r[3]:6d}  barrier {r[5]-r[4]:6d}  total {r[5]-r[0]:6d}")
