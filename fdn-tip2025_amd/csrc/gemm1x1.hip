@@ -48,7 +48,7 @@ __device__ __forceinline__ void bstore(float v, rsrc_t r, unsigned voff, unsigne
 }
 
 template <int MT, int PRO, int NW, bool EARLY>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? 3 : 1) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? (MT <= 2 ? 3 : 2) : 1) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = NW * 64;
     constexpr int WS = MT * 32 + 1;            // LDS row stride of the transposed weight chunk
@@ -171,7 +171,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? 3 : 1) void conv1x1_
             x_issue(cur, 0, xa, ya);
         }
         int step = 0;
+#ifdef FDN_GEMM_TRACE   // tools/gemm_trace.py: per-step s_memtime stamps of waves 0 and 4 of workgroup 0 into d.mul (vec4 = 12345)
+        unsigned long long* trc = (d.vec4 == 12345 && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+                                      ? reinterpret_cast<unsigned long long*>(const_cast<float*>(d.mul)) + (wave ? 1024 : 0) : nullptr;
+#define TRC(i) if (trc && step < 120) trc[step * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define TRC(i)
+#endif
         while (live) {
+            TRC(0)
             // next step
             int ntile = tile, nc = c + 1;
             if (nc == nch) { nc = 0; ntile = tile + gridDim.x; }
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? 3 : 1) void conv1x1_
                 }
             }
 
+            TRC(1)
             // ---- compute step (tile, c) -----------------------------------------------------------
             const float* Wc = Wl + (g.resident ? c : (step & 1)) * CH;
 #pragma unroll
@@ -232,6 +241,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? 3 : 1) void conv1x1_
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[m * 32], bv, acc[m], 0, 0, 0);
             }
 
+            TRC(2)
             // ---- epilogue at the last chunk of a tile --------------------------------------------------
             if (c == nch - 1) {
                 if (cur.ok) {
@@ -327,10 +337,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? 3 : 1) void conv1x1_
                     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
             }
 
+            TRC(3)
             if (!g.resident) {
                 if (nlive) w_stash((step + 1) & 1);
+                TRC(4)
                 __syncthreads();
             }
+            TRC(5)
             // advance
             if (nlive && nc == 0) { cur = nxt; stats_load(cur); }
 #pragma unroll
@@ -734,6 +747,9 @@ int launch_early(const fdn_conv1x1_desc& d, hipStream_t s) {
     // measured (tools/gpu_gemm_shapes.py): 64-wide plain GEMMs (FDFFN project_out at level 2, 172 -> 64) gain from
     // 4-wave workgroups at 3 waves per SIMD (13.5 -> 10.9 ms); wider tiles spill at that register budget
     if constexpr (MT == 2 && PRO == FDN_PRO_NONE) return launch<MT, PRO, 4, false>(d, s);
+    // wide tiles: two independent 4-wave workgroups per CU instead of one of 8 - their per-chunk barriers drift apart,
+    // so one workgroup's MFMAs fill the other's load-issue / barrier phase (345 -> 128: 12.1 -> 11.3 ms)
+    if constexpr (MT >= 3) return launch<MT, PRO, 4, false>(d, s);
     return launch<MT, PRO, 8, false>(d, s);
 }
 
@@ -742,7 +758,9 @@ int launch_pro(const fdn_conv1x1_desc& d, hipStream_t s) {
     switch (d.pro) {
         case FDN_PRO_NONE: return launch_early<MT, FDN_PRO_NONE>(d, s);
         case FDN_PRO_LN: return launch_early<MT, FDN_PRO_LN>(d, s);
-        case FDN_PRO_LN3_GATE: return launch<MT, FDN_PRO_LN3_GATE, 8, false>(d, s);
+        case FDN_PRO_LN3_GATE:
+            if constexpr (MT >= 3) return launch<MT, FDN_PRO_LN3_GATE, 4, false>(d, s);
+            return launch<MT, FDN_PRO_LN3_GATE, 8, false>(d, s);
         case FDN_PRO_LN_MULADD: return launch_early<MT, FDN_PRO_LN_MULADD>(d, s);
         default: return FDN_ERR_ARG;
     }
@@ -764,7 +782,9 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
     if (d.epi == FDN_EPI_RES) FDN_CHECK_ARG(d.res);
     if (d.epi == FDN_EPI_MULADD) FDN_CHECK_ARG(d.mul && d.add);
     if (d.stats_out) FDN_CHECK_ARG(d.N <= 160);
+#ifndef FDN_GEMM_TRACE
     d.vec4 = 0;
+#endif
     // 32-bit buffer offsets: every per-image plane set must stay below 4 GiB (incl. the padded K / N tails)
     {
         const unsigned long long lim = 0xFFFFFFFFull, P4 = 4ull * d.P;

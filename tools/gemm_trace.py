@@ -16,7 +16,14 @@ d = Conv1x1Desc()
 d.x[0] = p(x); d.xbs[0] = K * P; d.kseg[0] = K
 d.w = p(w); d.out = p(out); d.obs = N * P; d.B, d.K, d.N, d.P = B, K, N, P
 d.pro = 0; d.epi = 1; d.res = p(res); d.rbs = N * P; d.act = 0
-d.gamma = p(trace); d.vec4 = 12345
+d.mul = p(trace); d.vec4 = 12345
+if len(sys.argv) > 3 and sys.argv[3] == "ln3":          # LN3_GATE prologue: K = 3E, x = o[:, :3E], xb = o[:, 3E:]
+    from fdn_hip import ops
+    E = K // 3
+    o = torch.randn(B, 4 * E, H, W, device=dev)
+    st3 = ops.chan_stats(o[:, :3 * E], groups=3); g3 = torch.randn(3 * E, device=dev); b3 = torch.randn(3 * E, device=dev)
+    d.x[0] = p(o); d.xbs[0] = 4 * E * P; d.pro = 2; d.ln_group = E
+    d.stats = p(st3); d.gamma = p(g3); d.beta = p(b3); d.xb = ctypes.c_void_p(o.data_ptr() + 3 * E * P * 4); d.xbbs = 4 * E * P
 for _ in range(2):
     rc = fdn_hip.lib().fdn_conv1x1(ctypes.byref(d), fdn_hip.stream()); assert rc == 0, rc
 torch.cuda.synchronize()
