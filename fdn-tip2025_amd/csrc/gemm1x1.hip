@@ -55,8 +55,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? (MT <= 2 ? 3 : 2) : 
     constexpr int CH = KC * WS;                // floats per chunk buffer
     const int K = d.K, N = d.N;
     const unsigned P = (unsigned)d.P, P4 = P * 4u;
-    const int nch = (K + KC - 1) / KC;
+    // LN3_GATE walks K = 3E as (e, E+e, 2E+e) triples, 5 channel pairs e = 2j+kh per chunk (15 k-steps): the three
+    // k-steps of a triple share one v_value operand (a third of the loads and registers of the plain k order) and
+    // their LayerNorm group is a compile-time constant
+    constexpr bool TRI = PRO == FDN_PRO_LN3_GATE;
+    constexpr int KS = TRI ? 15 : 16;          // MFMA k-steps per chunk
+    const int E = d.ln_group;
+    const int nch = TRI ? ((E + 1) / 2 + 4) / 5 : (K + KC - 1) / KC;
     const int Kp = nch * KC;
+    auto kbase = [&](int c_, int s_) { return TRI ? (s_ % 3) * E + 2 * (c_ * 5 + s_ / 3) : c_ * KC + 2 * s_; };   // even-lane k of a step
     float* tg = smem;                          // gamma[Kp]
     float* tb = smem + Kp;                     // beta[Kp]
     float* Wl = smem + 2 * Kp;                 // weight chunks
@@ -70,7 +77,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? (MT <= 2 ? 3 : 2) : 
         tb[i] = (PRO != FDN_PRO_NONE && i < K) ? d.beta[i] : 0.f;
     }
 
-    const int E = d.ln_group;
     const int ks0 = d.kseg[0], ks01 = d.kseg[0] + d.kseg[1];
     const int npass = (N + MT * 32 - 1) / (MT * 32);
     constexpr int WPT = (KC * MT * 32) / NT;   // weight elements per thread per chunk
@@ -81,11 +87,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? (MT <= 2 ? 3 : 2) : 
         // ---- weight chunk loader: W[n][k] (lanes along k) -> regs -> Wl[buf][k][n] ---------------
         float wr[WPT];
         auto w_fetch = [&](int c) {
-            const int kk = tid & 31, k = c * KC + kk;
+            const int kk = tid & 31;           // LDS row = 2 * k-step + lane half
+            const int k = kbase(c, kk >> 1) + (kk & 1);
+            const bool kok = TRI ? ((kk >> 1) < KS && 2 * (c * 5 + (kk >> 1) / 3) + (kk & 1) < E) : k < K;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 const int n = nbase + (tid >> 5) + (NT / 32) * i;
-                wr[i] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
+                wr[i] = (n < N && kok) ? d.w[(long)n * K + k] : 0.f;
             }
         };
         auto w_stash = [&](int buf) {
@@ -126,20 +134,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? (MT <= 2 ? 3 : 2) : 
             const rsrc_t r2 = mk_rsrc(d.x[2] + (long)t.b * d.xbs[2], (unsigned)d.kseg[2] * P4);
             const unsigned voff = (kh * P + t.pix) * 4u;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int k = c_ * KC + 2 * s;                      // wave-uniform, even
-                if (k < ks0) xv[s] = bload(r0, voff, (unsigned)k * P4);
+            for (int s = 0; s < KS; ++s) {
+                const int k = kbase(c_, s);                         // wave-uniform
+                if (TRI || k < ks0) xv[s] = bload(r0, voff, (unsigned)k * P4);      // (LN3_GATE: one segment; k >= K reads 0)
                 else if (k < ks01) xv[s] = bload(r1, voff, (unsigned)(k - ks0) * P4);
                 else xv[s] = bload(r2, voff, (unsigned)(k - ks01) * P4);
             }
             if (PRO == FDN_PRO_LN3_GATE) {
                 const rsrc_t ry = mk_rsrc(d.xb + (long)t.b * d.xbbs, (unsigned)E * P4);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int k = c_ * KC + 2 * s + kh;
-                    const int e = k - ((k >= E) + (k >= 2 * E)) * E;
-                    yv[s] = bload(ry, ((unsigned)e * P + t.pix) * 4u, 0u);
-                }
+                for (int j = 0; j < 5; ++j) yv[j] = bload(ry, voff, (unsigned)(2 * (c_ * 5 + j)) * P4);   // v_value[e], e = 2j + kh
             } else if (PRO == FDN_PRO_LN_MULADD) {
                 const rsrc_t ry = mk_rsrc(d.xb + (long)t.b * d.xbbs, (unsigned)K * P4);
 #pragma unroll
@@ -219,18 +223,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? (MT <= 2 ? 3 : 2) : 
             // ---- compute step (tile, c) -----------------------------------------------------------
             const float* Wc = Wl + (g.resident ? c : (step & 1)) * CH;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 float bv = xa[s];
                 if (PRO != FDN_PRO_NONE) {
-                    const int k = c * KC + 2 * s + kh;
+                    const int k = min(kbase(c, s) + kh, Kp - 1);    // (tables are zero past K)
                     const float ga = tg[k], be = tb[k];
                     if (PRO == FDN_PRO_LN) {
                         bv = (bv - mu[0]) * rs[0] * ga + be;
                     } else if (PRO == FDN_PRO_LN3_GATE) {
-                        const int q = (k >= E) + (k >= 2 * E);
-                        const float m_ = q == 0 ? mu[0] : (q == 1 ? mu[1] : mu[2]);
-                        const float r_ = q == 0 ? rs[0] : (q == 1 ? rs[1] : rs[2]);
-                        bv = ((bv - m_) * r_ * ga + be) * ya[s];
+                        bv = ((bv - mu[s % 3]) * rs[s % 3] * ga + be) * ya[s / 3];
                     } else {
                         bv = ((bv - mu[0]) * rs[0] * ga + be) * ya[s] + ya[s];
                     }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? (MT <= 2 ? 3 : 2) : 
                     // (tools/gemm_trace.py)
                     // batch size by register budget: MT = 1 lives on 128 registers (2 workgroups per CU); the wide LN3_GATE
                     // kernels sit at 256 already and keep the one-by-one form
-                    constexpr int EB = MT == 1 ? 4 : ((PRO == FDN_PRO_LN3_GATE && MT >= 3) ? 1 : 16);
+                    constexpr int EB = MT == 1 ? 4 : 16;
                     if constexpr (EB == 1) {
 #pragma unroll
                         for (int m = 0; m < MT; ++m)
@@ -632,7 +633,7 @@ int g_num_cu = 0;
 
 template <int MT, int PRO, int NW, bool EARLY>
 int launch(const fdn_conv1x1_desc& d, hipStream_t s) {
-    const int nch = (d.K + KC - 1) / KC;
+    const int nch = PRO == FDN_PRO_LN3_GATE ? ((d.ln_group + 1) / 2 + 4) / 5 : (d.K + KC - 1) / KC;   // as in the kernel
     const size_t tab = 2UL * nch * KC * sizeof(float);
     const size_t chunk = (size_t)KC * (MT * 32 + 1) * sizeof(float);
     Geo g;
