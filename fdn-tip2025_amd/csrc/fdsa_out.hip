@@ -135,6 +135,12 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_kernel(FoArgs a) {
             const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
             const unsigned vo = (4u * kh * P + pix) * 4u;
             float sm = 0.f;
+            // the residual operand is requested as one batch before the stores: interleaved with them every load is
+            // waited for on its own (16 memory round trips per tile instead of one; tools/gemm_trace.py)
+            float rres[MT * 16];
+#pragma unroll
+            for (int i = 0; i < MT * 16; ++i)
+                rres[i] = bload(rr, vo, (unsigned)((i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2)) * P4);   // 0 without a residual
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_kernel(FoArgs a) {
                     const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
                     const unsigned so = (unsigned)nrow * P4;
                     float v = acc[m][r];
-                    if (a.res) v += bload(rr, vo, so);
+                    v += rres[m * 16 + r];
                     bstore(v, ro, vo, so);
                     v = (nrow + 4 * kh < N) ? v : 0.f;
                     acc[m][r] = v;

@@ -48,7 +48,7 @@ __device__ __forceinline__ void bstore(float v, rsrc_t r, unsigned voff, unsigne
 }
 
 template <int MT, int PRO, int NW, bool EARLY>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? (MT <= 2 ? 3 : 2) : 1) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? ((MT <= 2 && PRO == FDN_PRO_NONE) ? 3 : 2) : 1) void conv1x1_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = NW * 64;
     constexpr int WS = MT * 32 + 1;            // LDS row stride of the transposed weight chunk
@@ -760,7 +760,7 @@ int launch_pro(const fdn_conv1x1_desc& d, hipStream_t s) {
         case FDN_PRO_NONE: return launch_early<MT, FDN_PRO_NONE>(d, s);
         case FDN_PRO_LN: return launch_early<MT, FDN_PRO_LN>(d, s);
         case FDN_PRO_LN3_GATE:
-            if constexpr (MT >= 3) return launch<MT, FDN_PRO_LN3_GATE, 4, false>(d, s);
+            if constexpr (MT >= 2) return launch<MT, FDN_PRO_LN3_GATE, 4, false>(d, s);
             return launch<MT, FDN_PRO_LN3_GATE, 8, false>(d, s);
         case FDN_PRO_LN_MULADD: return launch_early<MT, FDN_PRO_LN_MULADD>(d, s);
         default: return FDN_ERR_ARG;
