@@ -12,7 +12,6 @@
 namespace {
 
 constexpr int KC = 32;
-constexpr int NW = 8;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -33,8 +32,8 @@ struct C3Args {
     int tiles_per_img, total_tiles;
 };
 
-template <int MT>
-__global__ __launch_bounds__(NW * 64) void conv3x3_kernel(C3Args a) {
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_kernel(C3Args a) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];
     constexpr int NT = NW * 64;
     constexpr int WS = MT * 32 + 1;
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_kernel(C3Args a) {
 
 int g_cus = 0;
 
-template <int MT>
+template <int MT, int NW>
 int launch(C3Args a, hipStream_t s) {
     const size_t lds = 2UL * KC * (MT * 32 + 1) * sizeof(float);
     if (g_cus == 0) {
@@ -177,9 +176,13 @@ int launch(C3Args a, hipStream_t s) {
     }
     a.tiles_per_img = cdiv((long)a.H * a.W, NW * 32);
     a.total_tiles = a.B * a.tiles_per_img;
-    int grid = g_cus * 2;
+    // 4-wave workgroups, two (independent) per CU: their per-chunk barriers drift apart (as in gemm1x1.hip)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(conv3x3_kernel<MT, NW>), NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu * NW > 16) per_cu = 16 / NW;
+    int grid = g_cus * per_cu;
     if (grid > a.total_tiles) grid = a.total_tiles;
-    hipLaunchKernelGGL(conv3x3_kernel<MT>, dim3(grid), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_kernel<MT, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
     return fdn_launch_status();
 }
 
@@ -198,8 +201,8 @@ int fdn_conv3x3_mfma(const float* x, const float* w, const float* bias, const fl
     a.act = act; a.res_before_act = res_before_act; a.post_add = post_add;
     a.tiles_per_img = a.total_tiles = 0;
     const int tiles = (Cout + 31) / 32;
-    if (tiles == 1) return launch<1>(a, s);
-    if (tiles == 2) return launch<2>(a, s);
-    if (tiles == 3) return launch<3>(a, s);
-    return launch<4>(a, s);
+    if (tiles == 1) return launch<1, 4>(a, s);
+    if (tiles == 2) return launch<2, 4>(a, s);
+    if (tiles == 3) return launch<3, 4>(a, s);
+    return launch<4, 4>(a, s);
 }
