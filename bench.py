@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the per-GPU batch is split over")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-GPU batch is split over (measured best: 3)")
     ap.add_argument("--scatter-gather", action="store_true", help="time RCCL scatter of inputs / gather of outputs too")
     ap.add_argument("--variant", choices=("lolblur", "lolv1"), default="lolblur",
                     help="lolblur = FDN (BASELINE.json's metric); lolv1 = FDN_lolv1, dim 24 (SURVEY.md 8(f) rank 1)")
