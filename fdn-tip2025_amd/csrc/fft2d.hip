@@ -89,6 +89,91 @@ bool make_plan(int N, int tabN, Plan* p) {
     return p->tw != nullptr;
 }
 
+// Rader's algorithm for a prime length p whose p-1 factors into the radices above (641 = W/2 of the
+// (W+2)-wide maps of fourier_fuse at 720p, FDN_arch.py:126,139): with a primitive root g,
+//   X[g^-q] = x[0] + sum_m x[g^m] * w^(g^(m-q)),  w = e^{-2 pi i / p}
+// is a cyclic convolution of length p-1, done with two Stockham FFTs of length p-1 and a pointwise product
+// with the precomputed spectrum of b[m] = w^(g^-m) (scaled by 1/(p-1)); X[0] = x[0] + sum_m x[g^m].
+struct Rader {
+    int p;                     // 0 = unused
+    const int* perm_in;        // [p-1]  g^q mod p
+    const int* perm_out;       // [p-1]  g^-q mod p
+    const float2* bhat;        // [p-1]  FFT_{p-1}(b) / (p-1)
+    Plan sub;                  // length p-1, its own table (tab_mul 1)
+};
+std::map<std::pair<int, int>, Rader> g_rader;
+
+bool is_prime(int n) {
+    if (n < 2) return false;
+    for (int f = 2; (long)f * f <= n; ++f)
+        if (n % f == 0) return false;
+    return true;
+}
+
+// returns false when p is not prime / p-1 needs a radix without a register butterfly (caller keeps the gather pass)
+bool get_rader(int p, Rader* out) {
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return false;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_rader.find({devid, p});
+        if (it != g_rader.end()) { *out = it->second; return out->p != 0; }
+    }
+    Rader r = {};
+    auto fail = [&]() { std::lock_guard<std::mutex> lk(g_mu); g_rader[{devid, p}] = Rader{}; return false; };
+    if (p < 29 || !is_prime(p)) return fail();
+    const int n = p - 1;
+    if (!make_plan(n, n, &r.sub)) return fail();
+    for (int i = 0; i < r.sub.nst; ++i) {
+        const int R = r.sub.radix[i];
+        if (!(R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 17 || R == 23)) return fail();
+    }
+    auto powmod = [&](long b, long e) { long x = 1; b %= p; while (e) { if (e & 1) x = x * b % p; b = b * b % p; e >>= 1; } return x; };
+    int g = 0;
+    for (int c = 2; c < p && !g; ++c) {
+        bool ok = true;
+        int m = n;
+        for (int f = 2; f <= m && ok; ++f)
+            if (m % f == 0) { if (powmod(c, n / f) == 1) ok = false; while (m % f == 0) m /= f; }
+        if (ok) g = c;
+    }
+    if (!g) return fail();
+    const long ginv = powmod(g, p - 2);
+    std::vector<int> pin(n), pout(n);
+    long a = 1, b = 1;
+    for (int q = 0; q < n; ++q) { pin[q] = (int)a; pout[q] = (int)b; a = a * g % p; b = b * ginv % p; }
+    std::vector<double> br(n), bi(n);
+    for (int m = 0; m < n; ++m) {                     // b[m] = w^(g^-m)
+        const double ang = -2.0 * M_PI * (double)pout[m] / (double)p;
+        br[m] = cos(ang); bi[m] = sin(ang);
+    }
+    std::vector<float2> bh(n);
+    for (int k = 0; k < n; ++k) {                     // plain DFT in double: n^2 = 4e5 terms, once per (device, p)
+        double sr = 0, si = 0;
+        for (int m = 0; m < n; ++m) {
+            const double ang = -2.0 * M_PI * (double)((long)k * m % n) / (double)n;
+            const double c = cos(ang), sn = sin(ang);
+            sr += br[m] * c - bi[m] * sn;
+            si += br[m] * sn + bi[m] * c;
+        }
+        bh[k] = make_float2((float)(sr / n), (float)(si / n));
+    }
+    int *dpi = nullptr, *dpo = nullptr;
+    float2* dbh = nullptr;
+    if (hipMalloc(&dpi, sizeof(int) * n) != hipSuccess || hipMalloc(&dpo, sizeof(int) * n) != hipSuccess ||
+        hipMalloc(&dbh, sizeof(float2) * n) != hipSuccess)
+        return fail();
+    if (hipMemcpy(dpi, pin.data(), sizeof(int) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dpo, pout.data(), sizeof(int) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dbh, bh.data(), sizeof(float2) * n, hipMemcpyHostToDevice) != hipSuccess)
+        return fail();
+    r.p = p; r.perm_in = dpi; r.perm_out = dpo; r.bhat = dbh;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_rader[{devid, p}] = r;
+    *out = r;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------
 // device: Stockham passes over sequences held in LDS
 //   element idx of sequence s lives at  s*ss + idx*es
@@ -348,13 +433,16 @@ __device__ void fft_run_inplace(float2* buf, const Plan& p, const float2* tw, in
 // ------------------------------------------------------------------------------------------
 template <bool BIG>
 __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__ in, float2* __restrict__ out, int W, long R,
-                                                       int rpb, const Plan p) {
+                                                       int rpb, const Plan p, const Rader rd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = W / 2, Wf = M + 1;
     float2* A = reinterpret_cast<float2*>(smem);
     float2* Bf = A + (long)rpb * M;
     float2* twl = Bf + (long)rpb * M;
+    float2* tws = twl + W;                              // Rader: table of the length M-1 sub-transform, then x[0] per row
     for (int i = threadIdx.x; i < W; i += NT) twl[i] = p.tw[i];
+    if (rd.p)
+        for (int i = threadIdx.x; i < M - 1; i += NT) tws[i] = rd.sub.tw[i];
     const long row0 = (long)blockIdx.x * rpb;
     const int nrow = (int)min((long)rpb, R - row0);
 #pragma unroll 8
@@ -362,7 +450,43 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
         const int s = idx / M, m = idx - s * M;
         A[idx] = (s < nrow) ? reinterpret_cast<const float2*>(in + (row0 + s) * W)[m] : make_float2(0.f, 0.f);
     }
-    float2* Z = fft_run<false, BIG>(A, Bf, p, twl, rpb, M, 1, false);
+    float2* Z;
+    if (rd.p) {
+        const int n = M - 1;
+        float2* z0 = tws + n;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < rpb * n; idx += NT) {           // a[q] = z[g^q]
+            const int s = idx / n, q = idx - s * n;
+            Bf[s * M + q] = A[s * M + rd.perm_in[q]];
+        }
+        if (threadIdx.x < rpb) z0[threadIdx.x] = A[threadIdx.x * M];
+        float2* Y = fft_run<false, BIG>(Bf, A, rd.sub, tws, rpb, M, 1, false);
+        float2* other = (Y == Bf) ? A : Bf;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < rpb * n; idx += NT) {           // spectrum of the convolution
+            const int s = idx / n, k = idx - s * n;
+            const float2 y = Y[s * M + k];
+            if (k == 0) other[s * M + n] = make_float2(z0[s].x + y.x, z0[s].y + y.y);   // X[0] = x[0] + sum a, parked in the spare slot
+            Y[s * M + k] = cmul(y, rd.bhat[k]);
+        }
+        __syncthreads();
+        float2 x0 = make_float2(0.f, 0.f);                                 // X[0] of row `threadIdx.x`, kept across the inverse
+        const bool keeper = threadIdx.x < rpb;
+        if (keeper) x0 = other[threadIdx.x * M + n];
+        float2* Cv = fft_run<true, BIG>(Y, other, rd.sub, tws, rpb, M, 1, false);
+        float2* dst = (Cv == Y) ? other : Y;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < rpb * n; idx += NT) {           // X[g^-q] = x[0] + c[q]
+            const int s = idx / n, q = idx - s * n;
+            const float2 c = Cv[s * M + q];
+            dst[s * M + rd.perm_out[q]] = make_float2(z0[s].x + c.x, z0[s].y + c.y);
+        }
+        if (keeper) dst[threadIdx.x * M] = x0;
+        __syncthreads();
+        Z = dst;
+    } else {
+        Z = fft_run<false, BIG>(A, Bf, p, twl, rpb, M, 1, false);
+    }
     // split: X[k] = E[k] + W_N^k O[k],  E = (Z[k]+conj Z[M-k])/2,  O = -i (Z[k]-conj Z[M-k])/2
     const int tw1 = p.tab_mul / 2;              // table is W_W^t:  tab_mul = W / M = 2  -> stride 1
 #pragma unroll 4
@@ -686,17 +810,20 @@ extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fd
     FDN_CHECK_ARG(in && out_c && rows > 0 && W >= 2 && W % 2 == 0);
     Plan p;
     if (!make_plan(W / 2, W, &p)) return FDN_ERR_UNSUPPORTED;
+    Rader rd = {};
+    const bool rader = p.nst == 1 && get_rader(W / 2, &rd);            // prime half-length: convolution form instead of the O(N^2) gather
+    if (!rader) rd = Rader{};
     const int rpb = pick_rpb(W / 2);
-    const size_t lds = (2UL * rpb * (W / 2) + W) * sizeof(float2);
+    const size_t lds = (2UL * rpb * (W / 2) + W + (rader ? (size_t)(W / 2) + rpb : 0)) * sizeof(float2);
     if (lds > 160 * 1024) return FDN_ERR_UNSUPPORTED;
-    if (plan_big(p)) {
+    if (plan_big(p) || (rader && plan_big(rd.sub))) {
         if (int e = set_lds(rfft_rows_kernel<true>, lds)) return e;
         hipLaunchKernelGGL(rfft_rows_kernel<true>, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream), in,
-                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p);
+                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p, rd);
     } else {
         if (int e = set_lds(rfft_rows_kernel<false>, lds)) return e;
         hipLaunchKernelGGL(rfft_rows_kernel<false>, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream), in,
-                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p);
+                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p, rd);
     }
     return fdn_launch_status();
 }
