@@ -445,10 +445,24 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
         for (int i = threadIdx.x; i < M - 1; i += NT) tws[i] = rd.sub.tw[i];
     const long row0 = (long)blockIdx.x * rpb;
     const int nrow = (int)min((long)rpb, R - row0);
-#pragma unroll 8
-    for (int idx = threadIdx.x; idx < rpb * M; idx += NT) {
-        const int s = idx / M, m = idx - s * M;
-        A[idx] = (s < nrow) ? reinterpret_cast<const float2*>(in + (row0 + s) * W)[m] : make_float2(0.f, 0.f);
+    {   // batches of unconditional loads (clamped address, value masked afterwards): with a branch per element hipcc
+        // waits for every load separately - one memory round trip per element
+        constexpr int U = 8;
+        const float2* in2 = reinterpret_cast<const float2*>(in + row0 * W);      // row s, element m at in2[s * M + m]
+        const int tot = rpb * M, live = nrow * M;
+        for (int base = threadIdx.x; base < tot; base += NT * U) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + NT * u;
+                v[u] = in2[idx < live ? idx : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + NT * u;
+                if (idx < tot) A[idx] = idx < live ? v[u] : make_float2(0.f, 0.f);
+            }
+        }
     }
     float2* Z;
     if (rd.p) {
@@ -524,15 +538,27 @@ __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict
     const long row0 = (long)blockIdx.x * rpb;
     const int nrow = (int)min((long)rpb, R - row0);
     const int tw1 = p.tab_mul / 2;
-#pragma unroll 4
-    for (int idx = threadIdx.x; idx < rpb * M; idx += NT) {
+    constexpr int UL = 4;
+    for (int base = threadIdx.x; base < rpb * M; base += NT * UL) {
+      float2 xks[UL], xcs[UL];
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {                               // batched, unconditional loads (clamped row)
+        const int idx = base + NT * u;
+        const int s = min(idx / M, nrow - 1), k = idx % M;
+        const long row = row0 + s;
+        const long plane = row / H, h = row - plane * H;
+        const float2* src = in + plane * in_plane_stride + h * in_ws;
+        xks[u] = src[k];
+        xcs[u] = src[M - k];
+      }
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        const int idx = base + NT * u;
+        if (idx >= rpb * M) continue;
         const int s = idx / M, k = idx - s * M;
         float2 z = make_float2(0.f, 0.f);
         if (s < nrow) {
-            const long row = row0 + s;
-            const long plane = row / H, h = row - plane * H;
-            const float2* src = in + plane * in_plane_stride + h * in_ws;
-            float2 xk = src[k], xc = src[M - k];
+            float2 xk = xks[u], xc = xcs[u];
             if (k == 0) { xk.y = 0.f; xc.y = 0.f; }            // c2r ignores Im of DC and Nyquist
             // E = (X[k] + conj X[M-k])/2 ; O = (X[k] - conj X[M-k])/2 * W_N^{-k} ; Z = E + i O
             const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));
@@ -542,21 +568,34 @@ __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict
             z = make_float2(e.x - o.y, e.y + o.x);
         }
         A[idx] = z;
+      }
     }
     float2* Z = fft_run<true, BIG>(A, Bf, p, twl, rpb, M, 1, false);
-#pragma unroll 4
-    for (int idx = threadIdx.x; idx < nrow * M; idx += NT) {
-        const int s = idx / M, m = idx - s * M;
-        const long row = row0 + s;
-        float2 v = Z[idx];
-        v.x *= scale;
-        v.y *= scale;
-        if (res) {
-            const float2 r = reinterpret_cast<const float2*>(res + row * W)[m];
-            v.x = fmaf(alpha, r.x, v.x);
-            v.y = fmaf(alpha, r.y, v.y);
+    {   // rows row0.. are contiguous in out / res: element idx of the block sits at float2 index row0 * M + idx
+        constexpr int US = 8;
+        const float2* res2 = res ? reinterpret_cast<const float2*>(res + row0 * W) : nullptr;
+        float2* out2 = reinterpret_cast<float2*>(out + row0 * W);
+        const int live = nrow * M;
+        for (int base = threadIdx.x; base < live; base += NT * US) {
+            float2 r[US];
+            if (res2) {
+#pragma unroll
+                for (int u = 0; u < US; ++u) r[u] = res2[min(base + NT * u, live - 1)];      // one batch, then the stores
+            }
+#pragma unroll
+            for (int u = 0; u < US; ++u) {
+                const int idx = base + NT * u;
+                if (idx >= live) continue;
+                float2 v = Z[idx];
+                v.x *= scale;
+                v.y *= scale;
+                if (res2) {
+                    v.x = fmaf(alpha, r[u].x, v.x);
+                    v.y = fmaf(alpha, r[u].y, v.y);
+                }
+                out2[idx] = v;
+            }
         }
-        reinterpret_cast<float2*>(out + row * W)[m] = v;
     }
 }
 
