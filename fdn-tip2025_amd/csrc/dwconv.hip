@@ -165,26 +165,64 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
 }
 
 // mul/add maps: per output channel c:  sum_tap w3[c][tap] * (sum_i w1[c][i] * img[i][p+tap])
+// The three image planes' halo tiles are fetched as one batch of buffer loads (zero outside the image, which is
+// what the zero padding of the depthwise conv sees since conv1 has no bias); a thread walks 8 rows of one column
+// with a sliding 3x3x3 window and evaluates the 8 channels of its workgroup per row.
 __global__ __launch_bounds__(256) void img_maps_kernel(const float* __restrict__ img, const float* __restrict__ w1m,
                                                        const float* __restrict__ w3m, const float* __restrict__ w1a,
                                                        const float* __restrict__ w3a, float* __restrict__ mul,
                                                        float* __restrict__ add, int C, int H, int W, int tiles_x) {
-    __shared__ float t[3][TH + 2][LS];
+    __shared__ float t[3][(TH + 2) * LS];
     const int b = blockIdx.z;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    const long hw = (long)H * W;
-    for (int i = 0; i < 3; ++i) load_halo(t[i], img + ((long)b * 3 + i) * hw, H, W, ty0, tx0);
-    __syncthreads();
-    const int cx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
-    const int gx = tx0 + cx;
-    if (gx >= W) return;
-    // channel chunk handled by this workgroup (blockIdx.y): 8 channels
-    const int c0 = blockIdx.y * 8;
-    for (int c = c0; c < min(c0 + 8, C); ++c) {
+    const unsigned hw4 = (unsigned)H * W * 4u;
+    const rsrc_t rin = mk_rsrc(img + (long)b * 3 * H * W, 3u * hw4);
+    {
+        float v[3][HPT];
+        int slot[HPT];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int gy = ty0 + r0 + r;
-            if (gy >= H) continue;
+        for (int i = 0; i < HPT; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            const int r = idx / LW, c = idx - r * LW;
+            const int y = ty0 - 1 + r, xx = tx0 - 1 + c;
+            const bool ok = idx < HALO && y >= 0 && y < H && xx >= 0 && xx < W;
+            const unsigned g = ok ? (unsigned)(y * W + xx) * 4u : OOB;
+            slot[i] = idx < HALO ? r * LS + c : -1;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) v[p][i] = bload(rin, g, (unsigned)p * hw4);
+        }
+#pragma unroll
+        for (int i = 0; i < HPT; ++i)
+            if (i < HPT - 1 || slot[i] >= 0) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) t[p][slot[i]] = v[p][i];
+            }
+    }
+    __syncthreads();
+    const int cx = threadIdx.x & 63;
+    const int r0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 8;
+    const int gx = tx0 + cx, gy0 = ty0 + r0;
+    const unsigned voff0 = (gx < W && gy0 < H) ? (unsigned)(gy0 * W + gx) * 4u : OOB;
+    const int rows_ok = H - gy0;
+    const unsigned row4 = (unsigned)W * 4u;
+    const rsrc_t rmul = mk_rsrc(mul + (long)b * C * H * W, (unsigned)C * hw4);
+    const rsrc_t radd = mk_rsrc(add + (long)b * C * H * W, (unsigned)C * hw4);
+    const int c0 = blockIdx.y * 8, nc = min(8, C - c0);               // channel chunk of this workgroup
+    float win[3][3][3];                                                 // [window row][plane][dx]
+    auto load_row = [&](int hr, int k) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) win[k][p][dx] = t[p][hr * LS + cx + dx];
+    };
+    load_row(r0, 0);
+    load_row(r0 + 1, 1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        load_row(r0 + r + 2, (r + 2) % 3);
+        if (r >= rows_ok) continue;                                     // wave-uniform
+        for (int cc = 0; cc < nc; ++cc) {
+            const int c = c0 + cc;
             float am = 0.f, aa = 0.f;
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
@@ -192,16 +230,15 @@ __global__ __launch_bounds__(256) void img_maps_kernel(const float* __restrict__
                 float sm = 0.f, sa = 0.f;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const float v = t[i][r0 + r + tp / 3][cx + tp % 3];
+                    const float v = win[(r + tp / 3) % 3][i][tp % 3];
                     sm = fmaf(w1m[c * 3 + i], v, sm);
                     sa = fmaf(w1a[c * 3 + i], v, sa);
                 }
                 am = fmaf(w3m[c * 9 + tp], sm, am);
                 aa = fmaf(w3a[c * 9 + tp], sa, aa);
             }
-            const long o = ((long)b * C + c) * hw + (long)gy * W + gx;
-            mul[o] = am;
-            add[o] = aa;
+            bstore(am, rmul, voff0, (unsigned)c * hw4 + (unsigned)r * row4);
+            bstore(aa, radd, voff0, (unsigned)c * hw4 + (unsigned)r * row4);
         }
     }
 }
@@ -230,6 +267,7 @@ extern "C" int fdn_img_mod_maps(const float* img, const float* w1_mul, const flo
                                 const float* w3_add, float* mul, float* add, int B, int C, int H, int W,
                                 fdn_stream_t stream) {
     FDN_CHECK_ARG(img && w1_mul && w3_mul && w1_add && w3_add && mul && add && B > 0 && C > 0 && H > 0 && W > 0);
+    FDN_CHECK_ARG(4ull * C * H * W < 0x80000000ull);          // one image's C planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     hipLaunchKernelGGL(img_maps_kernel, dim3(tx * ty, cdiv(C, 8), B), dim3(256), 0, static_cast<hipStream_t>(stream), img,
                        w1_mul, w3_mul, w1_add, w3_add, mul, add, C, H, W, tx);
