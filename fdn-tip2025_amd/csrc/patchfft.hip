@@ -137,7 +137,8 @@ __device__ __forceinline__ void halo_offsets(int H, int W, int y0, int x0, unsig
         const int y = y0 - 1 + rr, x = x0 - 1 + cc;
         const bool ok = idx < HALO && y >= 0 && y < H && x >= 0 && x < W;
         goff[i] = ok ? (unsigned)(y * W + x) * 4u : OOB;
-        slot[i] = idx < HALO ? rr * HS + cc : -1;
+        slot[i] = idx < HALO ? rr * HS + cc : (TH + 2) * HS;          // spare cell behind the tile (a conditional store
+                                                                         // lets hipcc sink the load into the branch: an extra round trip)
     }
 }
 __device__ __forceinline__ void halo_fetch(rsrc_t r, unsigned plane_off, const unsigned (&goff)[HPT], float (&v)[HPT]) {
@@ -146,8 +147,7 @@ __device__ __forceinline__ void halo_fetch(rsrc_t r, unsigned plane_off, const u
 }
 __device__ __forceinline__ void halo_stash(float* t, const int (&slot)[HPT], const float (&v)[HPT]) {
 #pragma unroll
-    for (int i = 0; i < HPT - 1; ++i) t[slot[i]] = v[i];
-    if (slot[HPT - 1] >= 0) t[slot[HPT - 1]] = v[HPT - 1];
+    for (int i = 0; i < HPT; ++i) t[slot[i]] = v[i];       // unconditional: slots past the tile point at a spare cell
 }
 // 3x3 stencil for the 8 pixels of row `row`, columns col0..col0+7 of the tile (halo origin -1,-1)
 __device__ __forceinline__ void stencil_row8(const float* t, int row, int col0, const float (&w)[9], float (&o)[8]) {
@@ -171,7 +171,7 @@ __device__ __forceinline__ void stencil_row8(const float* t, int row, int col0, 
 __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restrict__ hidden, const float* __restrict__ dww,
                                                            const float* __restrict__ fftw, float* __restrict__ out, int E,
                                                            int H, int W, int tiles_x) {
-    __shared__ float halo[2][(TH + 2) * HS];
+    __shared__ float halo[2][(TH + 2) * HS + 1];
     __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
 
     const int tid = threadIdx.x;
@@ -187,6 +187,14 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     const bool inside = gy < H && gx < W;          // patches are entirely inside or outside (H, W % 8 == 0)
     const unsigned ooff = inside ? (unsigned)(gy * W + gx) * 4u : OOB;
 
+    // the column-phase gains of this channel (thread = (patch, kx)) are requested first: their latency hides behind
+    // the whole row phase instead of stalling the column phase
+    float fg[8];
+    {
+        const int kxc = tid < NP * 5 ? tid % 5 : 0;
+#pragma unroll
+        for (int ky = 0; ky < 8; ++ky) fg[ky] = fftw[(e * 8 + ky) * 5 + kxc];
+    }
     unsigned goff[HPT];
     int slot[HPT];
     halo_offsets(H, W, ty0, tx0, goff, slot);
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
         float2 o1[8], o2[8], o3[8];
 #pragma unroll
         for (int ky = 0; ky < 8; ++ky) {
-            const float f = fftw[(e * 8 + ky) * 5 + kx];
+            const float f = fg[ky];
             const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));            // :591-593
             float2 qk = cmul(q[ky], k[ky]);                                               // :595
             qk = make_float2(rd1(qk.x), rd1(qk.y));                                       // :597
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
                                                            const float* __restrict__ w2, const float* __restrict__ ffta,
                                                            const float* __restrict__ fftp, float* __restrict__ out, int Hd,
                                                            int H, int W, int tiles_x) {
-    __shared__ float tin[(TH + 4) * LS2];           // halo 2
+    __shared__ float tin[(TH + 4) * LS2 + 1];       // halo 2 (+ spare cell)
     __shared__ float mid[(TH + 2) * LSM];           // gelu(dw0(x)) on halo 1
     __shared__ __attribute__((aligned(16))) float2 S[NP * PS];
     __shared__ float2 filt[40];                     // ffta * e^{-i fftp} per (ky, kx)
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
         const int y = ty0 - 2 + r, xx = tx0 - 2 + cc;
         const bool ok = idx < HALO2 && y >= 0 && y < H && xx >= 0 && xx < W;
         goff[i] = ok ? (unsigned)(y * W + xx) * 4u : OOB;
-        slot[i] = idx < HALO2 ? r * LS2 + cc : -1;
+        slot[i] = idx < HALO2 ? r * LS2 + cc : (TH + 4) * LS2;
     }
     float pre[HPT2];
     auto fetch = [&](int c) {
@@ -320,23 +328,29 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < HPT2 - 1; ++i) tin[slot[i]] = pre[i];
-        if (slot[HPT2 - 1] >= 0) tin[slot[HPT2 - 1]] = pre[HPT2 - 1];
+        for (int i = 0; i < HPT2; ++i) tin[slot[i]] = pre[i];   // unconditional (spare cell for slots past the tile)
     };
     fetch(cbase);
     stash();
     __syncthreads();
 
+    // (ffta, fftp) of the NEXT channel travel with its halo: loaded right here, in the middle of the loop, they would be
+    // waited for with vmcnt(0), which also drains the halo prefetch issued just before (the counter is in-order)
+    const int ftid = tid < 40 ? tid : 0;
+    float fa = ffta[cbase * 40 + ftid], fp = fftp[cbase * 40 + ftid];
     for (int ci = 0; ci < CPB; ++ci) {
         const int c = cbase + ci;
         if (c >= Hd) break;                                   // uniform
         const bool more = ci + 1 < CPB && c + 1 < Hd;
-        if (more) fetch(c + 1);                               // next channel's halo flies during this one's math
         if (tid < 40) {
             float sn, cs;
-            sincosf(fftp[c * 40 + tid], &sn, &cs);
-            const float a = ffta[c * 40 + tid];
-            filt[tid] = make_float2(a * cs, -a * sn);
+            fdn_sincos(fp, &sn, &cs);
+            filt[tid] = make_float2(fa * cs, -fa * sn);
+        }
+        if (more) {
+            fetch(c + 1);                                     // next channel's halo flies during this one's math
+            fa = ffta[(c + 1) * 40 + ftid];
+            fp = fftp[(c + 1) * 40 + ftid];
         }
         float k0[9], k2[9];
 #pragma unroll
