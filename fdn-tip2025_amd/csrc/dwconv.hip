@@ -73,17 +73,10 @@ constexpr int HPT = (HALO + 255) / 256;   // 9 halo elements per thread
 // input plane is read once instead of twice.  A thread walks 8 rows of one column with a sliding 3x3
 // window per plane (3 LDS reads per row and plane instead of 9).
 template <bool SAME>
-__device__ __forceinline__ void dw_gate_rows(const float* ta, const float* tb0, const float* tb1, const float* __restrict__ w, int C,
-                                             int j0, int j1, bool has1, int r0, int cx, rsrc_t rout, unsigned voff0,
-                                             unsigned row4, int rows_ok, unsigned plane0, unsigned plane1) {
-    float wa0[9], wb0[9], wa1[9], wb1[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        wa0[i] = w[j0 * 9 + i];
-        wb0[i] = w[(C + j0) * 9 + i];
-        wa1[i] = has1 ? w[j1 * 9 + i] : 0.f;
-        wb1[i] = has1 ? w[(C + j1) * 9 + i] : 0.f;
-    }
+__device__ __forceinline__ void dw_gate_rows(const float* ta, const float* tb0, const float* tb1, const float (&wa0)[9],
+                                             const float (&wb0)[9], const float (&wa1)[9], const float (&wb1)[9], bool has1, int r0,
+                                             int cx, rsrc_t rout, unsigned voff0, unsigned row4, int rows_ok, unsigned plane0,
+                                             unsigned plane1) {
     float a[3][3], p[3][3], q[3][3];
     auto load_row = [&](int hr, int k) {
 #pragma unroll
@@ -118,8 +111,8 @@ __device__ __forceinline__ void dw_gate_rows(const float* ta, const float* tb0, 
 
 __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       float* __restrict__ out, int C, int H, int W, int tiles_x) {
-    __shared__ float ta[(TH + 2) * LS];
-    __shared__ float tb[2][(TH + 2) * LS];
+    __shared__ float ta[(TH + 2) * LS + 1];
+    __shared__ float tb[2][(TH + 2) * LS + 1];
     const int m = blockIdx.y, b = blockIdx.z;
     const int j0 = 2 * m, j1 = 2 * m + 1;
     const bool has1 = j1 < C;
@@ -130,6 +123,14 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
     const rsrc_t rin = mk_rsrc(x + (long)b * C * H * W, (unsigned)C * hw4);
     const rsrc_t rout = mk_rsrc(out + (long)b * C * H * W, (unsigned)C * hw4);
 
+    float wa0[9], wb0[9], wa1[9], wb1[9];                   // scalar loads, requested ahead of the halo so both latencies overlap
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        wa0[i] = w[j0 * 9 + i];
+        wb0[i] = w[(C + j0) * 9 + i];
+        wa1[i] = has1 ? w[j1 * 9 + i] : 0.f;
+        wb1[i] = has1 ? w[(C + j1) * 9 + i] : 0.f;
+    }
     float va[HPT], vb[HPT], vc[HPT];
     int slot[HPT];
 #pragma unroll
@@ -139,18 +140,17 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
         const int y = ty0 - 1 + r, xx = tx0 - 1 + c;
         const bool ok = idx < HALO && y >= 0 && y < H && xx >= 0 && xx < W;
         const unsigned g = ok ? (unsigned)(y * W + xx) * 4u : OOB;
-        slot[i] = idx < HALO ? r * LS + c : -1;
+        slot[i] = idx < HALO ? r * LS + c : (TH + 2) * LS;     // spare cell: stores stay unconditional (no sunk load)
         va[i] = bload(rin, g, (unsigned)m * hw4);
         vb[i] = bload(rin, g, (unsigned)cb0 * hw4);
         vc[i] = same ? 0.f : bload(rin, g, (unsigned)cb1 * hw4);
     }
 #pragma unroll
-    for (int i = 0; i < HPT; ++i)
-        if (i < HPT - 1 || slot[i] >= 0) {
-            ta[slot[i]] = va[i];
-            tb[0][slot[i]] = vb[i];
-            if (!same) tb[1][slot[i]] = vc[i];
-        }
+    for (int i = 0; i < HPT; ++i) {
+        ta[slot[i]] = va[i];
+        tb[0][slot[i]] = vb[i];
+        if (!same) tb[1][slot[i]] = vc[i];
+    }
     __syncthreads();
     const int cx = threadIdx.x & 63;
     const int r0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 8;
@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
     const int rows_ok = H - gy0;                              // rows of this wave inside the image (>= 8: all)
     const unsigned row4 = (unsigned)W * 4u;
     if (same)
-        dw_gate_rows<true>(ta, tb[0], tb[0], w, C, j0, j1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hw4, (unsigned)j1 * hw4);
+        dw_gate_rows<true>(ta, tb[0], tb[0], wa0, wb0, wa1, wb1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hw4, (unsigned)j1 * hw4);
     else
-        dw_gate_rows<false>(ta, tb[0], tb[1], w, C, j0, j1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hw4, (unsigned)j1 * hw4);
+        dw_gate_rows<false>(ta, tb[0], tb[1], wa0, wb0, wa1, wb1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hw4, (unsigned)j1 * hw4);
 }
 
 // mul/add maps: per output channel c:  sum_tap w3[c][tap] * (sum_i w1[c][i] * img[i][p+tap])
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void img_maps_kernel(const float* __restrict__
                                                        const float* __restrict__ w3m, const float* __restrict__ w1a,
                                                        const float* __restrict__ w3a, float* __restrict__ mul,
                                                        float* __restrict__ add, int C, int H, int W, int tiles_x) {
-    __shared__ float t[3][(TH + 2) * LS];
+    __shared__ float t[3][(TH + 2) * LS + 1];
     const int b = blockIdx.z;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const unsigned hw4 = (unsigned)H * W * 4u;
@@ -187,16 +187,15 @@ __global__ __launch_bounds__(256) void img_maps_kernel(const float* __restrict__
             const int y = ty0 - 1 + r, xx = tx0 - 1 + c;
             const bool ok = idx < HALO && y >= 0 && y < H && xx >= 0 && xx < W;
             const unsigned g = ok ? (unsigned)(y * W + xx) * 4u : OOB;
-            slot[i] = idx < HALO ? r * LS + c : -1;
+            slot[i] = idx < HALO ? r * LS + c : (TH + 2) * LS;     // spare cell: unconditional stores
 #pragma unroll
             for (int p = 0; p < 3; ++p) v[p][i] = bload(rin, g, (unsigned)p * hw4);
         }
 #pragma unroll
-        for (int i = 0; i < HPT; ++i)
-            if (i < HPT - 1 || slot[i] >= 0) {
+        for (int i = 0; i < HPT; ++i) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) t[p][slot[i]] = v[p][i];
-            }
+            for (int p = 0; p < 3; ++p) t[p][slot[i]] = v[p][i];
+        }
     }
     __syncthreads();
     const int cx = threadIdx.x & 63;
