@@ -160,18 +160,23 @@ __global__ __launch_bounds__(NT) void ffn_tail_kernel(FtArgs a) {
             const unsigned vo = ok ? (unsigned)(4 * kh * hw + pix) * 4u : 0x80000000u;
             float sm = 0.f;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                float rres[16];                                      // residual operands of one 32-channel tile as a batch:
+#pragma unroll                                                       // next to the stores every load is waited for on its own
+                for (int r = 0; r < 16; ++r) rres[r] = bload(rr, vo, (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * hw4);   // 0 without res
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
                     const unsigned so = (unsigned)nrow * hw4;
                     float v = acc[m][r];
-                    if (a.res) v += bload(rr, vo, so);
+                    v += rres[r];
                     bstore(v, ro, vo, so);                           // rows >= N / pixels outside: dropped
                     v = (ok && nrow + 4 * kh < N) ? v : 0.f;
                     acc[m][r] = v;
                     sm += v;
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (a.stats_out) {
                 sm += __shfl_xor(sm, 32);
                 const float mean = sm / (float)N;

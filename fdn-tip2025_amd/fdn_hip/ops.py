@@ -156,10 +156,10 @@ def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None):
     """gate + project_out + residual (+ next LayerNorm statistics) in one launch (fdn_ffn_tail)."""
     B, C, H, W = y.shape
     N = w.shape[0]
-    # measured on MI355X (tools/bench_kernels.py tail, B=8 720p): since the gate kernel walks a sliding 3x3
-    # window (1.28 ms at level 1) the two-launch form (gate kernel + MFMA GEMM) beats the fused launch at
-    # every level (L3 FDFFN 1.12 vs 1.31 ms, L1 2.50 vs 3.90 ms); the fused kernel stays selectable
-    fused = mode == "fused"
+    # measured on MI355X (tools/bench_kernels.py tail, B=8 720p): with the sliding-window gate kernel the two-launch
+    # form (gate kernel + MFMA GEMM) beats the fused launch almost everywhere (level 1: 2.24 vs 3.17 ms, level 3:
+    # 0.91 vs 1.11 ms); the fused kernel wins only for the 64 -> 64 FCAFFN tail of level 2 (0.72 vs 0.87 ms)
+    fused = (C == 64 and N == 64) if mode is None else mode == "fused"
     if not fused:
         g = dwconv_gate(y, dw_w)
         return conv1x1(g, w, res=res, want_stats=want_stats)
