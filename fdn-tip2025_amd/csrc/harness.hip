@@ -43,7 +43,51 @@ __global__ __launch_bounds__(256) void post_u8_kernel(const float* __restrict__ 
     o[2] = swap_rb ? v[0] : v[2];
 }
 
+// Tiled inference (ImageRestorationModel.grids / grids_inverse, image_restoration_model.py:261-339, scale 1):
+// gather: tile t = x[:, i_t : i_t + ch, j_t : j_t + cw]; merge: every output pixel adds the tiles covering it in tile
+// order (the order of the reference's accumulation loop, so the fp32 sum is the same) and divides by their count.
+__global__ __launch_bounds__(256) void tiles_gather_kernel(const float* __restrict__ x, float* __restrict__ tiles,
+                                                           const int* __restrict__ ij, int C, int H, int W, int ch, int cw) {
+    const int px = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, t = blockIdx.z;
+    if (px >= ch * cw) return;
+    const int y = px / cw, xx = px - y * cw;
+    const int i = ij[2 * t], j = ij[2 * t + 1];
+    tiles[(((long)t * C + c) * ch + y) * cw + xx] = x[((long)c * H + i + y) * W + j + xx];
+}
+
+__global__ __launch_bounds__(256) void tiles_merge_kernel(const float* __restrict__ tiles, float* __restrict__ out,
+                                                          const int* __restrict__ ij, int T, int C, int H, int W, int ch, int cw) {
+    const int px = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (px >= H * W) return;
+    const int y = px / W, xx = px - y * W;
+    float acc = 0.f, cnt = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const int dy = y - ij[2 * t], dx = xx - ij[2 * t + 1];
+        if (dy >= 0 && dy < ch && dx >= 0 && dx < cw) {
+            acc += tiles[(((long)t * C + c) * ch + dy) * cw + dx];
+            cnt += 1.0f;
+        }
+    }
+    out[(long)c * H * W + px] = acc / cnt;
+}
+
 }  // namespace
+
+extern "C" int fdn_tiles_gather(const float* x, float* tiles, const int* ij, int T, int C, int H, int W, int ch, int cw,
+                                fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && tiles && ij && T > 0 && C > 0 && H > 0 && W > 0 && ch > 0 && cw > 0 && ch <= H && cw <= W && C < 65536 && T < 65536);
+    hipLaunchKernelGGL(tiles_gather_kernel, dim3(cdiv((long)ch * cw, 256), C, T), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       tiles, ij, C, H, W, ch, cw);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_tiles_merge(const float* tiles, float* out, const int* ij, int T, int C, int H, int W, int ch, int cw,
+                               fdn_stream_t stream) {
+    FDN_CHECK_ARG(tiles && out && ij && T > 0 && C > 0 && H > 0 && W > 0 && ch > 0 && cw > 0 && ch <= H && cw <= W && C < 65536);
+    hipLaunchKernelGGL(tiles_merge_kernel, dim3(cdiv((long)H * W, 256), C), dim3(256), 0, static_cast<hipStream_t>(stream), tiles, out,
+                       ij, T, C, H, W, ch, cw);
+    return fdn_launch_status();
+}
 
 extern "C" int fdn_pre_u8(const unsigned char* img, float* out, int B, int h, int w, int H, int W, int swap_rb,
                           fdn_stream_t stream) {

@@ -192,6 +192,14 @@ int fdn_gamma_curve(const float* x, const float* i_map, float* out, float scale,
 int fdn_pre_u8(const unsigned char* img, float* out, int B, int h, int w, int H, int W, int swap_rb, fdn_stream_t stream);
 int fdn_post_u8(const float* res, unsigned char* out, int B, int h, int w, int H, int W, int swap_rb, fdn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Tiled inference (ImageRestorationModel.grids / grids_inverse,
+ * basicsr/models/image_restoration_model.py:261-339, scale = 1).  ij = device int32 [T][2] tile origins (i, j).
+ * fdn_tiles_gather: x [C][H][W] -> tiles [T][C][ch][cw].
+ * fdn_tiles_merge : tiles [T][C][ch][cw] -> out [C][H][W] = (sum of the tiles covering a pixel, in tile order) / count. */
+int fdn_tiles_gather(const float* x, float* tiles, const int* ij, int T, int C, int H, int W, int ch, int cw, fdn_stream_t stream);
+int fdn_tiles_merge(const float* tiles, float* out, const int* ij, int T, int C, int H, int W, int ch, int cw, fdn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -392,6 +392,50 @@ def harness_post(result, h, w):
     return a.astype("uint8")
 
 
+def grids_indices(h, w, crop_h, crop_w, scale=1):
+    """Tile origins of ImageRestorationModel.grids, image_restoration_model.py:261-312 (adaptive steps, the last
+    tile of a row / column is pulled back inside the image).  Returns (crop_h, crop_w, [(i, j), ...])."""
+    import math
+    crop_h, crop_w = crop_h // scale * scale, crop_w // scale * scale                       # :276
+    num_row, num_col = (h - 1) // crop_h + 1, (w - 1) // crop_w + 1                         # :278-279
+    step_j = crop_w if num_col == 1 else math.ceil((w - crop_w) / (num_col - 1) - 1e-8)     # :282
+    step_i = crop_h if num_row == 1 else math.ceil((h - crop_h) / (num_row - 1) - 1e-8)     # :283
+    step_i, step_j = step_i // scale * scale, step_j // scale * scale                       # :286-287
+    idx = []
+    i, last_i = 0, False
+    while i < h and not last_i:                                                             # :294-309
+        j = 0
+        if i + crop_h >= h:
+            i, last_i = h - crop_h, True
+        last_j = False
+        while j < w and not last_j:
+            if j + crop_w >= w:
+                j, last_j = w - crop_w, True
+            idx.append((i, j))
+            j += step_j
+        i += step_i
+    return crop_h, crop_w, idx
+
+
+def grids_split(x, crop_h, crop_w):
+    """grids(): (1,C,h,w) -> (T,C,crop_h,crop_w) tiles + origins (scale = 1), image_restoration_model.py:303-312."""
+    assert x.shape[0] == 1                                                                  # :265
+    ch, cw, idx = grids_indices(x.shape[2], x.shape[3], crop_h, crop_w)
+    return torch.cat([x[:, :, i:i + ch, j:j + cw] for i, j in idx], dim=0), idx
+
+
+def grids_merge(outs, idx, h, w):
+    """grids_inverse(): overlapping tiles are accumulated in order and divided by the coverage count,
+    image_restoration_model.py:315-339."""
+    T, C, ch, cw = outs.shape
+    preds = torch.zeros((1, C, h, w), dtype=outs.dtype)
+    count = torch.zeros((1, 1, h, w), dtype=outs.dtype)
+    for t, (i, j) in enumerate(idx):
+        preds[0, :, i:i + ch, j:j + cw] += outs[t]
+        count[0, 0, i:i + ch, j:j + cw] += 1.0
+    return preds / count
+
+
 def psnr(a, b, peak=1.0):
     """20*log10(peak/sqrt(mse)) (basicsr/metrics/psnr_ssim.py:59-63)."""
     mse = torch.mean((a.double() - b.double()) ** 2).item()

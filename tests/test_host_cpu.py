@@ -104,3 +104,16 @@ def test_lolv1_state_dict_layout_matches_reference():
     assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
     assert sd["net_p.patch_embed.proj.weight"].shape[0] == 24 and "net_a.net.Encoder.0.cat.weight" in sd
     net.load_state_dict(lolv1_weights(), strict=True)
+
+
+def test_tiling_origins_match_oracle_and_reject_cpu():
+    import torch
+    import fdn_hip
+    import fdn_oracle as O
+    from fdn_hip import tiling
+    for (h, w, ch, cw) in ((720, 1280, 256, 256), (100, 150, 64, 64), (96, 96, 96, 96), (1088, 1920, 512, 640)):
+        assert tiling.tile_origins(h, w, ch, cw) == O.grids_indices(h, w, ch, cw)[2]
+    with pytest.raises(fdn_hip.FdnHipError):
+        tiling.split(torch.zeros(1, 3, 64, 64), 32, 32)
+    with pytest.raises(fdn_hip.FdnHipError):
+        tiling.tile_origins(64, 64, 128, 32)

@@ -184,3 +184,17 @@ def test_lolv1_harness_u8():
     out = O.harness_post(res, h, w)
     diff = (out.astype(int) - fx["out_u8"].numpy().astype(int))
     assert abs(diff).max() <= 1 and (diff != 0).mean() < 1e-2
+
+
+# ---- tiled inference (grids / grids_inverse) ------------------------------------------
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_grids_against_reference_methods(case):
+    """Fixture = the reference's own grids()/grids_inverse() code run on a stub model (tests/golden/make_golden_grids.py)."""
+    import numpy as np
+    z = np.load(__import__("os").path.join(__import__("common").GOLDEN, "grids.npz"))
+    x, (ch, cw) = torch.from_numpy(z[case + "_x"]), z[case + "_crop"]
+    tiles, idx = O.grids_split(x, int(ch), int(cw))
+    assert [list(t) for t in idx] == z[case + "_idx"].tolist()
+    assert torch.equal(tiles, torch.from_numpy(z[case + "_tiles"]))
+    merged = O.grids_merge(torch.from_numpy(z[case + "_outs"]), idx, x.shape[2], x.shape[3])
+    assert torch.equal(merged, torch.from_numpy(z[case + "_merged"]))
