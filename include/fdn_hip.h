@@ -200,6 +200,16 @@ int fdn_post_u8(const float* res, unsigned char* out, int B, int h, int w, int H
 int fdn_tiles_gather(const float* x, float* tiles, const int* ij, int T, int C, int H, int W, int ch, int cw, fdn_stream_t stream);
 int fdn_tiles_merge(const float* tiles, float* out, const int* ij, int T, int C, int H, int W, int ch, int cw, fdn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Validation metrics on the GPU (basicsr/metrics/psnr_ssim.py:8-73, :163-197).
+ * fdn_sse_max: out2[0] += sum (a-b)^2 in fp64, out2[1] = max(out2[1], max(a)) over n floats (caller zeroes out2);
+ *   PSNR = 20 log10(peak / sqrt(out2[0] / n)), peak = 1 if max <= 1 else 255 (:58-61).
+ * fdn_ssim3d: the ssim3d=True path of calculate_ssim on [C][H][W] fp32 images: *out_sum += sum of the SSIM map over
+ *   the (H, W, C) volume (mean = sum / (C*H*W)); ws = 10*C*H*W floats of workspace (caller zeroes out_sum). */
+int fdn_sse_max(const float* a, const float* b, long n, double* out2, fdn_stream_t stream);
+int fdn_ssim3d(const float* a, const float* b, int C, int H, int W, float max_value, float* ws, double* out_sum,
+               fdn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -436,6 +436,48 @@ def grids_merge(outs, idx, h, w):
     return preds / count
 
 
+def gaussian_kernel_11():
+    """cv2.getGaussianKernel(11, 1.5) (OpenCV, not vendored by the reference; unpinned version): for ksize > 7 or an
+    explicit sigma it is exp(-(i - (ksize-1)/2)^2 / (2 sigma^2)) normalised to sum 1, in float64."""
+    i = torch.arange(11, dtype=torch.float64) - 5.0
+    k = torch.exp(-(i * i) / (2.0 * 1.5 * 1.5))
+    return k / k.sum()
+
+
+def calculate_psnr(img1, img2, crop_border=0):
+    """basicsr/metrics/psnr_ssim.py:8-73 for (C,H,W) tensors, test_y_channel=False: float64 MSE, peak by img1.max()."""
+    a, b = img1.to(torch.float64), img2.to(torch.float64)
+    if crop_border:
+        a, b = a[..., crop_border:-crop_border, crop_border:-crop_border], b[..., crop_border:-crop_border, crop_border:-crop_border]
+    mse = torch.mean((a - b) ** 2).item()
+    if mse == 0:
+        return float("inf")
+    peak = 1.0 if a.max().item() <= 1 else 255.0
+    import math
+    return 20.0 * math.log10(peak / math.sqrt(mse))
+
+
+def ssim_3d(img1, img2, crop_border=0):
+    """calculate_ssim(ssim3d=True) -> _ssim_3d, psnr_ssim.py:163-197: an 11x11x11 Gaussian window (outer product of three
+    getGaussianKernel(11,1.5)) over the (H, W, C) volume with replicate padding, in float32; mean of the SSIM map."""
+    a, b = img1.to(torch.float64), img2.to(torch.float64)
+    if crop_border:
+        a, b = a[..., crop_border:-crop_border, crop_border:-crop_border], b[..., crop_border:-crop_border, crop_border:-crop_border]
+    max_value = 1 if a.max().item() <= 1 else 255
+    C1, C2 = (0.01 * max_value) ** 2, (0.03 * max_value) ** 2
+    k = gaussian_kernel_11()
+    window = torch.outer(k, k)
+    kern = torch.stack([window * kk for kk in k], dim=0).to(torch.float32)[None, None]        # (1,1,11,11,11): :151-156
+    x = a.permute(1, 2, 0).to(torch.float32)[None, None]                                       # (H, W, C) volume
+    y = b.permute(1, 2, 0).to(torch.float32)[None, None]
+    conv = lambda t: F.conv3d(F.pad(t, (5, 5, 5, 5, 5, 5), mode="replicate"), kern)
+    mu1, mu2 = conv(x), conv(y)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 ** 2, mu2 ** 2, mu1 * mu2
+    s1, s2, s12 = conv(x * x) - mu1_sq, conv(y * y) - mu2_sq, conv(x * y) - mu1_mu2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return float(ssim_map.mean())
+
+
 def psnr(a, b, peak=1.0):
     """20*log10(peak/sqrt(mse)) (basicsr/metrics/psnr_ssim.py:59-63)."""
     mse = torch.mean((a.double() - b.double()) ** 2).item()

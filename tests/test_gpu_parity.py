@@ -413,3 +413,18 @@ def test_forward_tiled_matches_oracle(A):
         outs = O.fdn_forward(fdn_weights(tame=0.03), tiles, O.lpnet_forward(lpnet_weights(), tiles))[0]
     ref = O.grids_merge(outs, idx, 96, 128)
     assert O.psnr(got.cpu(), ref) > 95.0
+
+
+def test_metrics_kernels(A):
+    """fdn_sse_max / fdn_ssim3d against the reference-generated values: PSNR is an fp64 reduction (1e-9 dB), the 3-D SSIM
+    window is applied as three separable fp32 passes instead of one 1331-tap fp32 convolution (2e-5)."""
+    from test_oracle_golden import _metric_cases
+    from fdn_hip import metrics
+    for name, x, y, ref in _metric_cases():
+        assert abs(metrics.calculate_psnr(dev(x), dev(y), ref["crop_border"]) - ref["psnr"]) < 1e-9, name
+        assert abs(metrics.calculate_ssim(dev(x), dev(y), ref["crop_border"]) - ref["ssim"]) < 2e-5, name
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(1, 3, 736, 1280, generator=g)
+    b = (a + 0.02 * torch.randn(a.shape, generator=g)).clamp(0, 1)
+    assert abs(metrics.calculate_psnr(dev(a), dev(b)) - O.calculate_psnr(a[0], b[0])) < 1e-9
+    assert metrics.calculate_psnr(dev(a), dev(a)) == float("inf")

@@ -198,3 +198,21 @@ def test_grids_against_reference_methods(case):
     assert torch.equal(tiles, torch.from_numpy(z[case + "_tiles"]))
     merged = O.grids_merge(torch.from_numpy(z[case + "_outs"]), idx, x.shape[2], x.shape[3])
     assert torch.equal(merged, torch.from_numpy(z[case + "_merged"]))
+
+
+def _metric_cases():
+    import json
+    import os
+    import numpy as np
+    from common import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    cases = json.loads(bytes(z["cases_json"]).decode())
+    return [(k, torch.from_numpy(z[k + "_x"]), torch.from_numpy(z[k + "_y"]), v) for k, v in cases.items()]
+
+
+def test_metrics_against_reference_functions():
+    """calculate_psnr / _ssim_3d of the oracle against values produced by the reference's own functions
+    (tests/golden/make_golden_metrics.py)."""
+    for name, x, y, ref in _metric_cases():
+        assert abs(O.calculate_psnr(x, y, ref["crop_border"]) - ref["psnr"]) < 1e-9, name
+        assert abs(O.ssim_3d(x, y, ref["crop_border"]) - ref["ssim"]) < 1e-6, name
