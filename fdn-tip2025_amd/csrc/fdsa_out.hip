@@ -40,7 +40,7 @@ constexpr int NW = 4;
 
 // SH = ceil(E/2) k-steps per group, MT = ceil(N/32)
 template <int SH, int MT>
-__global__ __launch_bounds__(NW * 64, 2) void fdsa_out_kernel(FoArgs a) {
+__global__ __launch_bounds__(NW * 64, SH <= 19 ? 2 : 1) void fdsa_out_kernel(FoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int E2 = 2 * SH;
     constexpr int WS = MT * 32 + 1;
@@ -195,7 +195,7 @@ int launch(FoArgs a, hipStream_t s) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return FDN_ERR_LAUNCH;
     int per_cu = (int)((160 * 1024) / lds);
-    const int want = 2;
+    const int want = SH <= 19 ? 2 : 1;
     if (per_cu > want) per_cu = want;
     if (per_cu < 1) per_cu = 1;
     int grid = g_cus * per_cu;
@@ -218,5 +218,6 @@ extern "C" int fdn_fdsa_out(const float* o, const float* w, const float* gamma3,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int sh = (E + 1) / 2, mt = (N + 31) / 32;
     if (sh <= 19 && mt == 1) return launch<19, 1>(a, s);       // level 1: E = 38, C = 32
+    if (sh <= 38 && mt <= 2) return launch<38, 2>(a, s);       // level 2: E = 76, C = 64 (one wave per SIMD, 490 registers: 1.74 vs 1.88 ms)
     return FDN_ERR_UNSUPPORTED;                                  // caller falls back to stats + conv1x1
 }

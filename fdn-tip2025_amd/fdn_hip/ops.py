@@ -4,6 +4,7 @@ Inputs are fp32 ROCm tensors in NCHW layout.  A tensor argument may be a channel
 `t[:, a:b]` of a contiguous NCHW tensor (inner three dims dense, arbitrary batch stride).
 """
 import ctypes
+import os
 
 import torch
 
@@ -130,7 +131,7 @@ def fdsa_out(o, w, gamma3, beta3, res=None, want_stats=False):
     """Fused FDSA tail (fdn_fdsa_out).  Returns None when the size is not covered (E > 76 or N > 64)."""
     B, C4, H, W = o.shape
     E, N, P = C4 // 4, w.shape[0], H * W
-    if E > 38 or N > 32:          # register-resident form: level 1 (and the dim-24 variant's level 1)
+    if E > 76 or N > 64:          # register-resident form: levels 1 and 2 (level 3 needs 612 values per pixel)
         return None
     out = torch.empty((B, N, H, W), device=o.device, dtype=torch.float32)
     stats = torch.empty((B, 1, 2, P), device=o.device, dtype=torch.float32) if want_stats else None
