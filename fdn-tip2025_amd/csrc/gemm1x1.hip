@@ -500,6 +500,153 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_kernel(fdn_conv1x1_des
     }
 }
 
+// Vectorised small-K variant (the HBM-bound level-1/2 to_hidden / project_in convs): a lane owns VEC consecutive
+// pixels, so every buffer load / store moves 16 (VEC = 4) or 8 (VEC = 2) bytes per lane and a half-wave touches 512 /
+// 256 contiguous bytes of a channel plane instead of 128 - the dword form stops at ~3.8 TB/s, 16-byte lanes reach ~5
+// (same effect as in norm.hip).  Register v of a loaded vector is the B operand of MFMA chain v; the VEC chains share
+// every A operand read from LDS.  Plain / LN prologue, no epilogue operand, one input segment, P % VEC == 0.
+template <int VEC> struct VecT;
+template <> struct VecT<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type bloadv(rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned uv __attribute__((ext_vector_type(VEC)));
+    uv u;
+    if constexpr (VEC == 4) u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    else u = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    typename VecT<VEC>::type f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = __uint_as_float(u[i]);
+    return f;
+}
+template <int VEC>
+__device__ __forceinline__ void bstorev(typename VecT<VEC>::type f, rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned uv __attribute__((ext_vector_type(VEC)));
+    uv u;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) u[i] = __float_as_uint(f[i]);
+    if constexpr (VEC == 4) __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(u, r, voff, soff, 0);
+}
+
+template <int NCH, int PRO, int VEC>
+__global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_desc d, Geo g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef typename VecT<VEC>::type vf;
+    constexpr int NT = 256, NWV = 4;
+    constexpr int Kp = NCH * KC, KS = NCH * 16;
+    const int K = d.K, N = d.N;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int ntiles = (N + 31) / 32;
+    const int NS = ntiles * 32 + 1;
+    float* tg = smem;
+    float* tb = smem + Kp;
+    float* Wl = smem + 2 * Kp;                 // [Kp][NS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+
+    for (int i = tid; i < Kp; i += NT) {
+        tg[i] = (PRO != FDN_PRO_NONE && i < K) ? d.gamma[i] : 0.f;
+        tb[i] = (PRO != FDN_PRO_NONE && i < K) ? d.beta[i] : 0.f;
+    }
+    for (int idx = tid; idx < Kp * ntiles * 32; idx += NT) {
+        const int k = idx % Kp, n = idx / Kp;
+        Wl[k * NS + n] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
+    }
+    __syncthreads();
+
+    struct Tile { int b; unsigned pix; bool ok; };
+    auto tile_setup = [&](int t) {
+        Tile r;
+        r.b = t / g.tiles_per_img;
+        const unsigned p_ = (unsigned)(t - r.b * g.tiles_per_img) * (NWV * 32 * VEC) + (wave * 32 + ln) * VEC;
+        r.ok = p_ < P;                          // P % VEC == 0: a vector is inside or outside as a whole
+        r.pix = r.ok ? p_ : P - VEC;
+        return r;
+    };
+    // ONE register set for the activation strip: the next tile's element s is requested into xa[s] right after the last
+    // MFMA group that reads it (during the last output tile), so no second (prefetch) buffer is live - with the LN
+    // prologue a double buffer does not fit two waves per SIMD at 16-byte lanes
+    vf xa[KS];
+    vf mu_n, rs_n;
+    auto stats_issue = [&](const Tile& t) {
+        if (PRO != FDN_PRO_NONE) {
+            const rsrc_t rs_ = mk_rsrc(d.stats + (long)t.b * 2 * P, 2u * P4);
+            mu_n = bloadv<VEC>(rs_, t.pix * 4u, 0u);
+            rs_n = bloadv<VEC>(rs_, t.pix * 4u, P4);
+        }
+    };
+
+    int tile = blockIdx.x;
+    bool live = tile < g.total_tiles;
+    Tile cur = tile_setup(live ? tile : 0);
+    if (live) {
+        const rsrc_t r0 = mk_rsrc(d.x[0] + (long)cur.b * d.xbs[0], (unsigned)K * P4);
+        const unsigned voff = (kh * P + cur.pix) * 4u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xa[s] = bloadv<VEC>(r0, voff, (unsigned)(2 * s) * P4);      // k >= K reads 0
+        stats_issue(cur);
+    }
+    while (live) {
+        if (PRO != FDN_PRO_NONE) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float ga = tg[2 * s + kh], be = tb[2 * s + kh];
+                xa[s] = (xa[s] - mu_n) * rs_n * ga + be;
+            }
+        }
+        const int ntile = tile + gridDim.x;
+        const bool nlive = ntile < g.total_tiles;
+        const Tile nxt = tile_setup(nlive ? ntile : tile);
+        const rsrc_t rn = mk_rsrc(d.x[0] + (long)nxt.b * d.xbs[0], (unsigned)K * P4);
+        const unsigned voffn = (kh * P + nxt.pix) * 4u;
+        if (nlive) stats_issue(nxt);                               // (mu, rstd) of the next tile: consumed after this one
+
+        const rsrc_t ro = mk_rsrc(d.out + (long)cur.b * d.obs, (unsigned)N * P4);
+        const unsigned voff = cur.ok ? (4u * kh * P + cur.pix) * 4u : 0x80000000u;     // outside pixels: stores dropped
+        for (int m = 0; m < ntiles; ++m) {
+            const bool refill = nlive && m == ntiles - 1;
+            f32x16 acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+            // A operands one group of 8 k-steps ahead (as mfma_chain); each feeds VEC MFMAs
+            const float* w = Wl + kh * NS + m * 32 + ln;
+            float a[2][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[0][i] = w[i * 2 * NS];
+#pragma unroll
+            for (int grp = 0; grp < KS / 8; ++grp) {
+                if (grp + 1 < KS / 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a[(grp + 1) & 1][i] = w[((grp + 1) * 8 + i) * 2 * NS];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][i], xa[grp * 8 + i][v], acc[v], 0, 0, 0);
+                if (refill) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xa[grp * 8 + i] = bloadv<VEC>(rn, voffn, (unsigned)(2 * (grp * 8 + i)) * P4);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                vf o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o[v] = acc[v][r];
+                if (d.bias) { const int n = nrow + 4 * kh; o += (n < N) ? d.bias[n] : 0.f; }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
+                bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);        // rows >= N fall outside the descriptor
+            }
+        }
+        cur = nxt; tile = ntile; live = nlive;
+    }
+}
+
 // Small-K, large-N variant whose weight matrix does NOT fit LDS (level 3: 128 -> 612 / 345): same
 // register-resident activation strip, but the 32-channel weight tiles stream through a double
 // buffer in LDS (one barrier per output tile).  The strip of the NEXT pixel tile is requested a
@@ -714,6 +861,46 @@ int launch_smallk_stream(const fdn_conv1x1_desc& d, hipStream_t s) {
     return fdn_launch_status();
 }
 
+template <int NCH, int PRO, int VEC>
+int launch_smallk_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
+    const int ntiles = (d.N + 31) / 32;
+    const size_t lds = (2UL * NCH * KC + (size_t)NCH * KC * (ntiles * 32 + 1)) * sizeof(float);
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    Geo g;
+    g.resident = 1;
+    g.tiles_per_img = cdiv(d.P, 4 * 32 * VEC);
+    g.total_tiles = d.B * g.tiles_per_img;
+    auto kern = conv1x1_smallk_vec_kernel<NCH, PRO, VEC>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return FDN_ERR_LAUNCH;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    int grid = g_num_cu * per_cu;
+    if (grid > g.total_tiles) grid = g.total_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, d, g);
+    return fdn_launch_status();
+}
+
+// the vectorised kernel covers: small-K shapes (see smallk_ok) with one segment, no epilogue operand, plain / LN prologue,
+// P a multiple of 4 and 16-byte aligned tensors
+bool smallk_vec_ok(const fdn_conv1x1_desc& d) {
+    if (d.kseg[1] > 0 || d.kseg[2] > 0 || d.epi != FDN_EPI_NONE || (d.pro != FDN_PRO_NONE && d.pro != FDN_PRO_LN)) return false;
+    if (d.P % 4 != 0 || d.xbs[0] % 4 != 0 || d.obs % 4 != 0) return false;
+    uintptr_t a = reinterpret_cast<uintptr_t>(d.x[0]) | reinterpret_cast<uintptr_t>(d.out);
+    if (d.pro != FDN_PRO_NONE) a |= reinterpret_cast<uintptr_t>(d.stats);
+    return (a & 15) == 0;
+}
+
 // K <= 128, N >= 2K, single input segment, plain/LN prologue, no muladd epilogue, weights too big for LDS
 bool smallk_stream_ok(const fdn_conv1x1_desc& d) {
     if (d.K > 128 || d.K <= 64 || d.stats_out || d.kseg[1] > 0) return false;
@@ -797,6 +984,20 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         const int nch = (d.K + KC - 1) / KC;
         if (d.pro == FDN_PRO_LN) return nch == 3 ? launch_smallk_stream<3, FDN_PRO_LN>(d, s) : launch_smallk_stream<4, FDN_PRO_LN>(d, s);
         return nch == 3 ? launch_smallk_stream<3, FDN_PRO_NONE>(d, s) : launch_smallk_stream<4, FDN_PRO_NONE>(d, s);
+    }
+    if (smallk_ok(d) && smallk_vec_ok(d)) {
+        // measured (tools/bench_kernels.py to_hidden ffn_in, B=8 720p): 8-byte lanes win for K <= 32 (32->152: 1.65 -> 1.44 ms,
+        // 32->86: 0.92 -> 0.76 ms) and for K <= 64 while the weight matrix leaves room for 3 workgroups per CU (64->172:
+        // 0.74 -> 0.59 ms; 64->304 is slower vectorised); 16-byte lanes spill with the LN prologue
+        const int ntiles = (d.N + 31) / 32;
+        if (d.K <= KC) {
+            if (d.pro == FDN_PRO_LN) return launch_smallk_vec<1, FDN_PRO_LN, 2>(d, s);
+            return launch_smallk_vec<1, FDN_PRO_NONE, 4>(d, s);
+        }
+        if ((2UL * 2 * KC + 2UL * KC * (ntiles * 32 + 1)) * sizeof(float) <= 52 * 1024) {
+            if (d.pro == FDN_PRO_LN) return launch_smallk_vec<2, FDN_PRO_LN, 2>(d, s);
+            return launch_smallk_vec<2, FDN_PRO_NONE, 2>(d, s);
+        }
     }
     if (smallk_ok(d)) {
         switch (d.pro) {
