@@ -38,9 +38,9 @@ if len(sys.argv) > 5:
     # it reads exactly Grid_Size * 32 * 4 bytes with 4-byte-per-lane coalesced loads
     f = glob.glob(sys.argv[5] + "/**/*counter_collection.csv", recursive=True)[0]
     row = [r for r in csv.DictReader(open(f)) if "chan_stats" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"][0]
-    exp = int(row["Grid_Size"]) * 32 * 4
+    exp = int(row["Grid_Size"]) * 32 * 4 * (4 if "chan_stats4" in row["Kernel_Name"] else 1)      # float4 form: 4 pixels per thread
     raw = float(row["Counter_Value"]) * 1024.0
-    out["fetch_calibration"] = {"kernel": "chan_stats_kernel (B=8, C=32, 736x1280)", "fetch_bytes_raw": raw, "expected_bytes": exp,
+    out["fetch_calibration"] = {"kernel": row["Kernel_Name"].split("(")[-2].split("::")[-1] + " (B=8, C=32, 736x1280)", "fetch_bytes_raw": raw, "expected_bytes": exp,
                                 "raw_over_expected": raw / exp,
                                 "note": "4-byte-per-lane coalesced loads: FETCH_SIZE reports half of the bytes, the same factor "
                                         "MI355X_MICROARCH.md gives for 16-byte lanes, so bench.py doubles fetch_GB_raw"}
