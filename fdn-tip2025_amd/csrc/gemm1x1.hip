@@ -529,7 +529,7 @@ __device__ __forceinline__ void bstorev(typename VecT<VEC>::type f, rsrc_t r, un
     else __builtin_amdgcn_raw_buffer_store_b64(u, r, voff, soff, 0);
 }
 
-template <int NCH, int PRO, int VEC>
+template <int NCH, int PRO, int VEC, bool TAIL>
 __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef typename VecT<VEC>::type vf;
@@ -631,16 +631,62 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                     for (int i = 0; i < 8; ++i) xa[grp * 8 + i] = bloadv<VEC>(rn, voffn, (unsigned)(2 * (grp * 8 + i)) * P4);
                 }
             }
+            if constexpr (!TAIL) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
-                vf o;
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                    vf o;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) o[v] = acc[v][r];
-                if (d.bias) { const int n = nrow + 4 * kh; o += (n < N) ? d.bias[n] : 0.f; }
+                    for (int v = 0; v < VEC; ++v) o[v] = acc[v][r];
+                    if (d.bias) { const int n = nrow + 4 * kh; o += (n < N) ? d.bias[n] : 0.f; }
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
-                bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);        // rows >= N fall outside the descriptor
+                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
+                    bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);        // rows >= N fall outside the descriptor
+                }
+            } else {
+                // TAIL (N <= 32, the narrow project_out convs): residual as one batch of vector loads, then the stores and
+                // the channel-LayerNorm statistics of the result (two-pass, registers only; lanes l and l^32 hold
+                // complementary rows of the same pixels)
+                vf rres[16], outv[16];
+                if (d.epi == FDN_EPI_RES) {
+                    const rsrc_t rr = mk_rsrc(d.res + (long)cur.b * d.rbs, (unsigned)N * P4);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rres[r] = bloadv<VEC>(rr, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * P4);
+                }
+                vf sm = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = (r & 3) + 8 * (r >> 2);
+                    vf o;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = acc[v][r];
+                    if (d.bias) { const int n = nrow + 4 * kh; o += (n < N) ? d.bias[n] : 0.f; }
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
+                    if (d.epi == FDN_EPI_RES) o += rres[r];
+                    bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);
+                    outv[r] = (nrow + 4 * kh < N) ? o : vf(0.f);
+                    sm += outv[r];
+                }
+                if (d.stats_out) {
+                    vf mean, sq = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) mean[v] = (sm[v] + __shfl_xor(sm[v], 32)) / (float)N;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const vf dl = outv[r] - mean;
+                        sq += ((r & 3) + 8 * (r >> 2) + 4 * kh < N) ? dl * dl : vf(0.f);
+                    }
+                    vf rstd;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) rstd[v] = 1.0f / sqrtf((sq[v] + __shfl_xor(sq[v], 32)) / (float)N + 1e-5f);
+                    if (kh == 0) {
+                        const rsrc_t rs_ = mk_rsrc(d.stats_out + (long)cur.b * 2 * P, 2u * P4);
+                        const unsigned vs = cur.ok ? cur.pix * 4u : 0x80000000u;
+                        bstorev<VEC>(mean, rs_, vs, 0u);
+                        bstorev<VEC>(rstd, rs_, vs, P4);
+                    }
+                }
             }
         }
         cur = nxt; tile = ntile; live = nlive;
@@ -861,7 +907,7 @@ int launch_smallk_stream(const fdn_conv1x1_desc& d, hipStream_t s) {
     return fdn_launch_status();
 }
 
-template <int NCH, int PRO, int VEC>
+template <int NCH, int PRO, int VEC, bool TAIL = false>
 int launch_smallk_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
     const int ntiles = (d.N + 31) / 32;
     const size_t lds = (2UL * NCH * KC + (size_t)NCH * KC * (ntiles * 32 + 1)) * sizeof(float);
@@ -875,7 +921,7 @@ int launch_smallk_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
     g.resident = 1;
     g.tiles_per_img = cdiv(d.P, 4 * 32 * VEC);
     g.total_tiles = d.B * g.tiles_per_img;
-    auto kern = conv1x1_smallk_vec_kernel<NCH, PRO, VEC>;
+    auto kern = conv1x1_smallk_vec_kernel<NCH, PRO, VEC, TAIL>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
@@ -907,6 +953,18 @@ bool smallk_stream_ok(const fdn_conv1x1_desc& d) {
     if (d.pro != FDN_PRO_NONE && d.pro != FDN_PRO_LN) return false;
     if (d.epi == FDN_EPI_MULADD) return false;
     return d.N >= 2 * d.K;
+}
+
+// narrow project_out convs for the vectorised kernel's TAIL form: K <= 96, N <= 32, no prologue, residual or no
+// epilogue operand, statistics allowed
+bool narrow_vec_ok(const fdn_conv1x1_desc& d) {
+    if (d.K > 96 || d.N > 32 || d.pro != FDN_PRO_NONE || d.kseg[1] > 0 || d.kseg[2] > 0) return false;
+    if (d.epi != FDN_EPI_NONE && d.epi != FDN_EPI_RES) return false;
+    if (d.P % 4 != 0 || d.xbs[0] % 4 != 0 || d.obs % 4 != 0 || (d.epi == FDN_EPI_RES && d.rbs % 4 != 0)) return false;
+    uintptr_t a = reinterpret_cast<uintptr_t>(d.x[0]) | reinterpret_cast<uintptr_t>(d.out);
+    if (d.epi == FDN_EPI_RES) a |= reinterpret_cast<uintptr_t>(d.res);
+    if (d.stats_out) a |= reinterpret_cast<uintptr_t>(d.stats_out);
+    return (a & 15) == 0;
 }
 
 // true when the small-K kernel covers this problem
@@ -984,6 +1042,11 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         const int nch = (d.K + KC - 1) / KC;
         if (d.pro == FDN_PRO_LN) return nch == 3 ? launch_smallk_stream<3, FDN_PRO_LN>(d, s) : launch_smallk_stream<4, FDN_PRO_LN>(d, s);
         return nch == 3 ? launch_smallk_stream<3, FDN_PRO_NONE>(d, s) : launch_smallk_stream<4, FDN_PRO_NONE>(d, s);
+    }
+    if (narrow_vec_ok(d)) {
+        if (d.K <= KC) return launch_smallk_vec<1, FDN_PRO_NONE, 2, true>(d, s);
+        if (d.K <= 2 * KC) return launch_smallk_vec<2, FDN_PRO_NONE, 2, true>(d, s);
+        return launch_smallk_vec<3, FDN_PRO_NONE, 2, true>(d, s);
     }
     if (smallk_ok(d) && smallk_vec_ok(d)) {
         // measured (tools/bench_kernels.py to_hidden ffn_in, B=8 720p): 8-byte lanes win for K <= 32 (32->152: 1.65 -> 1.44 ms,
