@@ -227,6 +227,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? ((MT <= 2 && PRO == 
                 float bv = xa[s];
                 if (PRO != FDN_PRO_NONE) {
                     const int k = min(kbase(c, s) + kh, Kp - 1);    // (tables are zero past K)
+                    asm volatile("" ::: "memory");                  // table reads stay inside the step (see conv1x1_smallk_vec_kernel)
                     const float ga = tg[k], be = tb[k];
                     if (PRO == FDN_PRO_LN) {
                         bv = (bv - mu[0]) * rs[0] * ga + be;
@@ -590,6 +591,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
         if (PRO != FDN_PRO_NONE) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
+                asm volatile("" ::: "memory");      // keeps the table reads here: hoisted out of the persistent tile loop (with
+                                                      // rs*gamma products precomputed per element) they cost ~130 registers
                 const float ga = tg[2 * s + kh], be = tb[2 * s + kh];
                 xa[s] = (xa[s] - mu_n) * rs_n * ga + be;
             }
@@ -995,7 +998,7 @@ int launch_early(const fdn_conv1x1_desc& d, hipStream_t s) {
     if constexpr (MT == 2 && PRO == FDN_PRO_NONE) return launch<MT, PRO, 4, false>(d, s);
     // wide tiles: two independent 4-wave workgroups per CU instead of one of 8 - their per-chunk barriers drift apart,
     // so one workgroup's MFMAs fill the other's load-issue / barrier phase (345 -> 128: 12.1 -> 11.3 ms)
-    if constexpr (MT >= 3) return launch<MT, PRO, 4, false>(d, s);
+    if constexpr (MT >= 3 && PRO != FDN_PRO_LN_MULADD) return launch<MT, PRO, 4, false>(d, s);     // (LN_MULADD spills at that budget)
     return launch<MT, PRO, 8, false>(d, s);
 }
 
@@ -1054,7 +1057,7 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         // 0.74 -> 0.59 ms; 64->304 is slower vectorised); 16-byte lanes spill with the LN prologue
         const int ntiles = (d.N + 31) / 32;
         if (d.K <= KC) {
-            if (d.pro == FDN_PRO_LN) return launch_smallk_vec<1, FDN_PRO_LN, 2>(d, s);
+            if (d.pro == FDN_PRO_LN) return launch_smallk_vec<1, FDN_PRO_LN, 2>(d, s);       // (16-byte lanes measure the same here)
             return launch_smallk_vec<1, FDN_PRO_NONE, 4>(d, s);
         }
         if ((2UL * 2 * KC + 2UL * KC * (ntiles * 32 + 1)) * sizeof(float) <= 52 * 1024) {
