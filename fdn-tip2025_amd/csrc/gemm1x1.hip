@@ -813,6 +813,144 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_stream_kernel(fdn_conv
     }
 }
 
+// 8-byte-lane form of the streaming small-K kernel (level-3 to_hidden / project_in, K <= 128): a lane owns two consecutive
+// pixels, the two MFMA chains share every A operand, ONE register set holds the strip (refilled for the next pixel tile
+// during the last output tile, as in conv1x1_smallk_vec_kernel; the dword kernel above keeps two sets and spills 88
+// registers at K = 128 with the LN prologue).  Plain / LN prologue, no epilogue operand.
+template <int NCH, int PRO>
+__global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv1x1_desc d, Geo g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int VEC = 2, NW = 8, NT = NW * 64;
+    typedef typename VecT<VEC>::type vf;
+    constexpr int Kp = NCH * KC, KS = NCH * 16;
+    constexpr int WS = 33;
+    constexpr int WPT = (Kp * 32) / NT;
+    const int K = d.K, N = d.N;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int ntiles = (N + 31) / 32;
+    float* tg = smem;
+    float* tb = smem + Kp;
+    float* Wl = smem + 2 * Kp;                 // [2][Kp][WS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+
+    for (int i = tid; i < Kp; i += NT) {
+        tg[i] = (PRO != FDN_PRO_NONE && i < K) ? d.gamma[i] : 0.f;
+        tb[i] = (PRO != FDN_PRO_NONE && i < K) ? d.beta[i] : 0.f;
+    }
+    float wr[WPT];
+    auto w_fetch = [&](int m) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int idx = tid + NT * i;
+            const int k = idx % Kp, n = m * 32 + idx / Kp;
+            wr[i] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
+        }
+    };
+    auto w_stash = [&](int buf) {
+        float* dst = Wl + buf * (Kp * WS);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int idx = tid + NT * i;
+            dst[(idx % Kp) * WS + idx / Kp] = wr[i];
+        }
+    };
+    w_fetch(0);
+    w_stash(0);
+    __syncthreads();
+
+    struct Tile { int b; unsigned pix; bool ok; };
+    auto tile_setup = [&](int t) {
+        Tile r;
+        r.b = t / g.tiles_per_img;
+        const unsigned p_ = (unsigned)(t - r.b * g.tiles_per_img) * (NW * 32 * VEC) + (wave * 32 + ln) * VEC;
+        r.ok = p_ < P;
+        r.pix = r.ok ? p_ : P - VEC;
+        return r;
+    };
+    vf xa[KS];
+    vf mu_n, rs_n;
+    auto stats_issue = [&](const Tile& t) {
+        if (PRO != FDN_PRO_NONE) {
+            const rsrc_t rs_ = mk_rsrc(d.stats + (long)t.b * 2 * P, 2u * P4);
+            mu_n = bloadv<VEC>(rs_, t.pix * 4u, 0u);
+            rs_n = bloadv<VEC>(rs_, t.pix * 4u, P4);
+        }
+    };
+    int tile = blockIdx.x;
+    bool live = tile < g.total_tiles;
+    Tile cur = tile_setup(live ? tile : 0);
+    if (live) {
+        const rsrc_t r0 = mk_rsrc(d.x[0] + (long)cur.b * d.xbs[0], (unsigned)K * P4);
+        const unsigned voff = (kh * P + cur.pix) * 4u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xa[s] = bloadv<VEC>(r0, voff, (unsigned)(2 * s) * P4);
+        stats_issue(cur);
+    }
+    int wstep = 0;
+    while (live) {
+        if (PRO != FDN_PRO_NONE) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                asm volatile("" ::: "memory");                     // table reads stay inside the tile loop
+                xa[s] = (xa[s] - mu_n) * rs_n * tg[2 * s + kh] + tb[2 * s + kh];
+            }
+        }
+        const int ntile = tile + gridDim.x;
+        const bool nlive = ntile < g.total_tiles;
+        const Tile nxt = tile_setup(nlive ? ntile : tile);
+        const rsrc_t rn = mk_rsrc(d.x[0] + (long)nxt.b * d.xbs[0], (unsigned)K * P4);
+        const unsigned voffn = (kh * P + nxt.pix) * 4u;
+        if (nlive) stats_issue(nxt);
+        const rsrc_t ro = mk_rsrc(d.out + (long)cur.b * d.obs, (unsigned)N * P4);
+        const unsigned voff = cur.ok ? (4u * kh * P + cur.pix) * 4u : 0x80000000u;
+        for (int m = 0; m < ntiles; ++m, ++wstep) {
+            const int mnext = (m + 1 < ntiles) ? m + 1 : 0;
+            const bool more = (m + 1 < ntiles) || nlive;
+            const bool refill = nlive && m == ntiles - 1;
+            if (more) w_fetch(mnext);                              // next weight tile: L2 -> registers
+            f32x16 acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+            const float* w = Wl + (wstep & 1) * (Kp * WS) + kh * WS + ln;
+            float a[2][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[0][i] = w[i * 2 * WS];
+#pragma unroll
+            for (int grp = 0; grp < KS / 8; ++grp) {
+                if (grp + 1 < KS / 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a[(grp + 1) & 1][i] = w[((grp + 1) * 8 + i) * 2 * WS];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][i], xa[grp * 8 + i][v], acc[v], 0, 0, 0);
+                if (refill) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xa[grp * 8 + i] = bloadv<VEC>(rn, voffn, (unsigned)(2 * (grp * 8 + i)) * P4);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                vf o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o[v] = acc[v][r];
+                if (d.bias) { const int n = nrow + 4 * kh; o += (n < N) ? d.bias[n] : 0.f; }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
+                bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);
+            }
+            if (more) w_stash((wstep + 1) & 1);
+            __syncthreads();
+        }
+        cur = nxt; tile = ntile; live = nlive;
+    }
+}
+
 int pick_mt(int N) {
     // fewest computed 32-row tiles, then fewest passes; MT <= 5 keeps the accumulator at 80 VGPRs
     const int tiles = (N + 31) / 32;
@@ -950,6 +1088,25 @@ bool smallk_vec_ok(const fdn_conv1x1_desc& d) {
     return (a & 15) == 0;
 }
 
+template <int NCH, int PRO>
+int launch_smallk_stream_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
+    const size_t lds = (2UL * NCH * KC + 2UL * NCH * KC * 33) * sizeof(float);
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    Geo g;
+    g.resident = 0;
+    g.tiles_per_img = cdiv(d.P, 8 * 32 * 2);
+    g.total_tiles = d.B * g.tiles_per_img;
+    int grid = g_num_cu;
+    if (grid > g.total_tiles) grid = g.total_tiles;
+    hipLaunchKernelGGL((conv1x1_smallk_stream_vec_kernel<NCH, PRO>), dim3(grid), dim3(512), lds, s, d, g);
+    return fdn_launch_status();
+}
+
 // K <= 128, N >= 2K, single input segment, plain/LN prologue, no muladd epilogue, weights too big for LDS
 bool smallk_stream_ok(const fdn_conv1x1_desc& d) {
     if (d.K > 128 || d.K <= 64 || d.stats_out || d.kseg[1] > 0) return false;
@@ -1041,6 +1198,11 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         if (d.kseg[1] > 0 && ((d.kseg[0] & 1) || (d.kseg[1] & 1))) return FDN_ERR_UNSUPPORTED;   // k-step pairs must not straddle segments
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (smallk_stream_ok(d) && d.epi == FDN_EPI_NONE && smallk_vec_ok(d)) {           // 128->612: 21.3 -> 20.0 ms, 128->345: 13.1 -> 10.9 ms
+        const int nch = (d.K + KC - 1) / KC;
+        if (d.pro == FDN_PRO_LN) return nch == 3 ? launch_smallk_stream_vec<3, FDN_PRO_LN>(d, s) : launch_smallk_stream_vec<4, FDN_PRO_LN>(d, s);
+        return nch == 3 ? launch_smallk_stream_vec<3, FDN_PRO_NONE>(d, s) : launch_smallk_stream_vec<4, FDN_PRO_NONE>(d, s);
+    }
     if (smallk_stream_ok(d)) {
         const int nch = (d.K + KC - 1) / KC;
         if (d.pro == FDN_PRO_LN) return nch == 3 ? launch_smallk_stream<3, FDN_PRO_LN>(d, s) : launch_smallk_stream<4, FDN_PRO_LN>(d, s);
