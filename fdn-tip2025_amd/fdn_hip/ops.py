@@ -34,6 +34,31 @@ def _flat(t, what):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_folded = {}
+
+
+def _fold_ln(w, bias, gamma, beta):
+    """w' = w * diag(gamma), bias' = w @ beta (+ bias): a LayerNorm's affine part in front of a 1x1 conv is linear in the
+    conv, so it is folded once per (weight, gamma, beta) version into the GEMM operands (FDN_PRO_LN then only
+    normalises).  Cached on the parameters' storage pointers and versions."""
+    key = (w.data_ptr(), w._version, gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version,
+           None if bias is None else (bias.data_ptr(), bias._version), str(w.device))
+    hit = _folded.get(key)
+    if hit is None:
+        with torch.no_grad():
+            w2 = w.reshape(w.shape[0], -1)
+            wf = (w2 * gamma.reshape(1, -1)).contiguous()
+            bf = torch.mv(w2.double(), beta.double()).float()
+            if bias is not None:
+                bf = bf + bias
+            # the source tensors are kept alive with the entry: their addresses (the key) cannot be reused while it exists
+            hit = (wf, bf.contiguous(), (w, gamma, beta, bias))
+        if len(_folded) > 1024:
+            _folded.clear()
+        _folded[key] = hit
+    return hit[0], hit[1]
+
+
 def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None, ln_muladd=None, res=None,
             muladd=None, want_stats=False):
     """1x1 conv with fused prologue/epilogue (fdn_conv1x1).
@@ -64,8 +89,10 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
     d.B, d.K, d.N, d.P = B, K, N, P
     d.pro, d.ln_group = PRO_NONE, K
     if ln is not None:
-        d.pro = PRO_LN
-        d.stats, d.gamma, d.beta = _flat(ln[0], "stats"), _flat(ln[1], "gamma"), _flat(ln[2], "beta")
+        d.pro = PRO_LN                        # the kernel normalises only; the affine part rides in the weights
+        w, bias = _fold_ln(w, bias, ln[1], ln[2])
+        d.w, d.bias = _flat(w, "w"), _flat(bias, "bias")
+        d.stats = _flat(ln[0], "stats")
     elif ln3_gate is not None:
         d.pro, d.ln_group = PRO_LN3_GATE, K // 3
         d.stats, d.gamma, d.beta = _flat(ln3_gate[0], "stats"), _flat(ln3_gate[1], "gamma"), _flat(ln3_gate[2], "beta")

@@ -42,8 +42,10 @@ const char* fdn_error_string(int code);
  * (:28), the residual adds (:671-675) and `x*mul+add` (:423).
  *   out[b][n][p] = epi( act( sum_k w[n][k] * pro(x[b][k][p]) + bias[n] ) )
  * x is the channel-concatenation of up to three segments (torch.cat at :137,:243,:250,:689).
- * pro: NONE | LN (stats/gamma/beta over K) | LN3_GATE (x = [o1|o2|o3] each ln_group channels,
- * three LayerNorms, times xb = v_value[ln_group]) | LN_MULADD (LN(x)*xb + xb).
+ * pro: NONE | LN ((x - mean) * rstd over K; the LayerNorm's affine part is linear and is folded by the caller:
+ * w = W * diag(gamma), bias = W * beta (+ bias) - gamma / beta are ignored) | LN3_GATE (x = [o1|o2|o3] each
+ * ln_group channels, three LayerNorms with gamma / beta [K], times xb = v_value[ln_group]) |
+ * LN_MULADD (LN(x)*xb + xb, gamma / beta [K]).
  * stats: [B][G][2][P] = (mean, rstd) from fdn_chan_stats, G = 3 for LN3_GATE else 1.
  * epi: NONE | RES (+res) | MULADD (*mul + add).  act is applied before epi. */
 typedef struct fdn_conv1x1_desc {

@@ -428,3 +428,30 @@ def test_metrics_kernels(A):
     b = (a + 0.02 * torch.randn(a.shape, generator=g)).clamp(0, 1)
     assert abs(metrics.calculate_psnr(dev(a), dev(b)) - O.calculate_psnr(a[0], b[0])) < 1e-9
     assert metrics.calculate_psnr(dev(a), dev(a)) == float("inf")
+
+
+@pytest.mark.parametrize("K,N,H,W", [(32, 152, 736, 1280), (32, 86, 736, 1280), (64, 304, 368, 640), (64, 172, 368, 640),
+                                     (128, 612, 184, 320), (128, 345, 184, 320), (86, 32, 736, 1280), (32, 32, 736, 1280),
+                                     (172, 64, 368, 640), (345, 128, 184, 320), (12, 12, 736, 1280)])
+def test_conv1x1_baseline_shapes_all_forms(A, K, N, H, W):
+    """Every kernel of the conv1x1 family at the real level-1/2/3 shapes of config 2 (the persistent tile loops, the
+    register-strip refill and the LDS tables only come into play at full size): plain, bias, folded LayerNorm
+    prologue, residual + statistics epilogue, against fp64."""
+    from fdn_hip import ops
+    x, w = _rnd(1, K, H, W, seed=K + N), _rnd(N, K, seed=K * N) / K ** 0.5
+    b, res, g, be = _rnd(N, seed=1), _rnd(1, N, H, W, seed=2), _rnd(K, seed=3), _rnd(K, seed=4)
+    xd, wd = dev(x), dev(w)
+    ref = torch.einsum("nk,bkhw->bnhw", w.double(), x.double())
+    assert rel_rms(ops.conv1x1(xd, wd).cpu(), ref) < 1e-6
+    assert rel_rms(ops.conv1x1(xd, wd, dev(b)).cpu(), ref + b.double().view(1, -1, 1, 1)) < 1e-6
+    xn = (x.double() - x.double().mean(1, keepdim=True)) / torch.sqrt(x.double().var(1, unbiased=False, keepdim=True) + 1e-5)
+    xn = xn * g.double().view(1, -1, 1, 1) + be.double().view(1, -1, 1, 1)
+    ref_ln = torch.einsum("nk,bkhw->bnhw", w.double(), xn)
+    assert rel_rms(ops.conv1x1(xd, wd, ln=(ops.chan_stats(xd), dev(g), dev(be))).cpu(), ref_ln) < 2e-6
+    got = ops.conv1x1(xd, wd, res=dev(res), want_stats=N <= 160)
+    tot = ref + res.double()
+    assert rel_rms(got.cpu(), tot) < 1e-6
+    if N <= 160:
+        st = got._fdn_stats.cpu().view(2, H, W).double()
+        assert (st[0] - tot.mean(1)[0]).abs().max() < 1e-5
+        assert rel_rms(st[1], 1.0 / torch.sqrt(tot.var(1, unbiased=False)[0] + 1e-5)) < 1e-5
