@@ -1215,6 +1215,12 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         if (d.kseg[1] > 0 && ((d.kseg[0] & 1) || (d.kseg[1] & 1))) return FDN_ERR_UNSUPPORTED;   // k-step pairs must not straddle segments
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // K = 64 with a weight matrix too big to sit in LDS three times per CU (level-2 to_hidden, 64 -> 304): stream the weights too
+    if (d.K > KC && d.K <= 2 * KC && d.N >= 256 && !d.stats_out && d.kseg[1] == 0 && d.epi == FDN_EPI_NONE &&
+        (d.pro == FDN_PRO_NONE || d.pro == FDN_PRO_LN) && smallk_vec_ok(d)) {               // 15.1 -> 12.4 ms
+        if (d.pro == FDN_PRO_LN) return launch_smallk_stream_vec<2, FDN_PRO_LN>(d, s);
+        return launch_smallk_stream_vec<2, FDN_PRO_NONE>(d, s);
+    }
     if (smallk_stream_ok(d) && d.epi == FDN_EPI_NONE && smallk_vec_ok(d)) {           // 128->612: 21.3 -> 20.0 ms, 128->345: 13.1 -> 10.9 ms
         const int nch = (d.K + KC - 1) / KC;
         if (d.pro == FDN_PRO_LN) return nch == 3 ? launch_smallk_stream_vec<3, FDN_PRO_LN>(d, s) : launch_smallk_stream_vec<4, FDN_PRO_LN>(d, s);
