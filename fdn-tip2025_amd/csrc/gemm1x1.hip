@@ -965,6 +965,171 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
     }
 }
 
+// 8-byte-lane form of the K-streaming kernel for the plain deep-K convs (FDFFN project_out at levels 2/3, Fuse):
+// a lane owns two consecutive pixels, so each A operand read from LDS feeds two MFMA chains per output tile and every
+// load / store moves 8 bytes per lane.  One input segment, no prologue, residual or no epilogue operand, statistics
+// of the result when N fits one pass.  Weights resident in LDS or double-buffered per 32-deep chunk, as the generic kernel.
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv1x1_kstream_vec_kernel(fdn_conv1x1_desc d, Geo g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int VEC = 2, NW = 4, NT = NW * 64;
+    typedef typename VecT<VEC>::type vf;
+    constexpr int WS = MT * 32 + 1;
+    constexpr int CH = KC * WS;
+    constexpr int WPT = (KC * MT * 32) / NT;
+    const int K = d.K, N = d.N;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int nch = (K + KC - 1) / KC;
+    float* Wl = smem;
+    float* bl = smem + g.bias_off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+    for (int i = tid; i < MT * 32; i += NT) bl[i] = (d.bias && i < N) ? d.bias[i] : 0.f;
+
+    float wr[WPT];
+    auto w_fetch = [&](int c) {
+        const int kk = tid & 31, k = c * KC + kk;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int n = (tid >> 5) + (NT / 32) * i;
+            wr[i] = (n < N && k < K) ? d.w[(long)n * K + k] : 0.f;
+        }
+    };
+    auto w_stash = [&](int buf) {
+        float* dst = Wl + buf * CH + (tid & 31) * WS;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) dst[(tid >> 5) + (NT / 32) * i] = wr[i];
+    };
+    if (g.resident) {
+        for (int c = 0; c < nch; ++c) { w_fetch(c); w_stash(c); }
+    } else {
+        w_fetch(0);
+        w_stash(0);
+    }
+    __syncthreads();
+
+    struct Tile { int b; unsigned pix; bool ok; };
+    auto tile_setup = [&](int t) {
+        Tile r;
+        r.b = t / g.tiles_per_img;
+        const unsigned p_ = (unsigned)(t - r.b * g.tiles_per_img) * (NW * 32 * VEC) + (wave * 32 + ln) * VEC;
+        r.ok = p_ < P;
+        r.pix = r.ok ? p_ : P - VEC;
+        return r;
+    };
+    vf xa[16], xb[16];
+    auto x_issue = [&](const Tile& t, int c_, vf (&xv)[16]) {
+        const rsrc_t r0 = mk_rsrc(d.x[0] + (long)t.b * d.xbs[0], (unsigned)K * P4);
+        const unsigned voff = (kh * P + t.pix) * 4u;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) xv[s_] = bloadv<VEC>(r0, voff, (unsigned)(c_ * KC + 2 * s_) * P4);   // k >= K reads 0
+    };
+    f32x16 acc[MT][VEC];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][v][r] = 0.f;
+
+    int tile = blockIdx.x, c = 0, step = 0;
+    bool live = tile < g.total_tiles;
+    Tile cur = tile_setup(live ? tile : 0);
+    if (live) x_issue(cur, 0, xa);
+    while (live) {
+        int ntile = tile, nc = c + 1;
+        if (nc == nch) { nc = 0; ntile = tile + gridDim.x; }
+        const bool nlive = ntile < g.total_tiles;
+        Tile nxt = cur;
+        if (nlive) {
+            if (nc == 0) nxt = tile_setup(ntile);
+            x_issue(nxt, nc, xb);
+            if (!g.resident) w_fetch(nc);
+        }
+        const float* Wc = Wl + (g.resident ? c : (step & 1)) * CH;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const float* wrow = Wc + (2 * s_ + kh) * WS + ln;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float a = wrow[m * 32];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[m][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xa[s_][v], acc[m][v], 0, 0, 0);
+            }
+        }
+        if (c == nch - 1) {
+            const unsigned nb4 = (unsigned)N * P4;
+            const rsrc_t ro = mk_rsrc(d.out + (long)cur.b * d.obs, nb4);
+            const rsrc_t rr = mk_rsrc(d.res ? d.res + (long)cur.b * d.rbs : d.out, d.res ? nb4 : 0u);
+            const unsigned voff = cur.ok ? (4u * kh * P + cur.pix) * 4u : 0x80000000u;
+            vf sm = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                vf l0[16];                                              // residual of one 32-channel tile as a batch
+                if (d.epi == FDN_EPI_RES) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) l0[r] = bloadv<VEC>(rr, voff, (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * P4);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                    vf o;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = acc[m][v][r];
+                    o += bl[nrow + 4 * kh];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
+                    if (d.epi == FDN_EPI_RES) o += l0[r];
+                    bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);
+                    o = (nrow + 4 * kh < N) ? o : vf(0.f);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[m][v][r] = o[v];
+                    sm += o;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (d.stats_out) {
+                vf mean, sq = 0.f, rstd;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) mean[v] = (sm[v] + __shfl_xor(sm[v], 32)) / (float)N;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool in = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < N;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            const float dl = acc[m][v][r] - mean[v];
+                            sq[v] += in ? dl * dl : 0.f;
+                        }
+                    }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) rstd[v] = 1.0f / sqrtf((sq[v] + __shfl_xor(sq[v], 32)) / (float)N + 1e-5f);
+                if (kh == 0) {
+                    const rsrc_t rs_ = mk_rsrc(d.stats_out + (long)cur.b * 2 * P, 2u * P4);
+                    const unsigned vs = cur.ok ? cur.pix * 4u : 0x80000000u;
+                    bstorev<VEC>(mean, rs_, vs, 0u);
+                    bstorev<VEC>(rstd, rs_, vs, P4);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][v][r] = 0.f;
+        }
+        if (!g.resident) {
+            if (nlive) w_stash((step + 1) & 1);
+            __syncthreads();
+        }
+        if (nlive && nc == 0) cur = nxt;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) xa[s_] = xb[s_];
+        tile = ntile; c = nc; live = nlive;
+        ++step;
+    }
+}
+
 int pick_mt(int N) {
     // fewest computed 32-row tiles, then fewest passes; MT <= 5 keeps the accumulator at 80 VGPRs
     const int tiles = (N + 31) / 32;
@@ -1123,6 +1288,48 @@ int launch_smallk_stream_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
     return fdn_launch_status();
 }
 
+template <int MT>
+int launch_kstream_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
+    const int nch = (d.K + KC - 1) / KC;
+    const size_t chunk = (size_t)KC * (MT * 32 + 1) * sizeof(float);
+    Geo g;
+    g.resident = (nch * chunk <= 64 * 1024) ? 1 : 0;
+    size_t lds = (g.resident ? nch : 2) * chunk;
+    g.bias_off = (int)(lds / sizeof(float));
+    lds += (size_t)MT * 32 * sizeof(float);
+    g.tiles_per_img = cdiv(d.P, 4 * 32 * 2);
+    g.total_tiles = d.B * g.tiles_per_img;
+    auto kern = conv1x1_kstream_vec_kernel<MT>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return FDN_ERR_LAUNCH;
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    int grid = g_num_cu * per_cu;
+    if (grid > g.total_tiles) grid = g.total_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, d, g);
+    return fdn_launch_status();
+}
+
+// plain deep-K convs for the 8-byte-lane K-streaming kernel
+bool kstream_vec_ok(const fdn_conv1x1_desc& d) {
+    if (d.pro != FDN_PRO_NONE || d.kseg[1] > 0 || d.kseg[2] > 0 || d.K <= 96 || d.N > 96) return false;   // (N = 128 spills: slower)
+    if (d.epi != FDN_EPI_NONE && d.epi != FDN_EPI_RES) return false;
+    if (d.P % 4 != 0 || d.xbs[0] % 4 != 0 || d.obs % 4 != 0 || (d.epi == FDN_EPI_RES && d.rbs % 4 != 0)) return false;
+    uintptr_t a = reinterpret_cast<uintptr_t>(d.x[0]) | reinterpret_cast<uintptr_t>(d.out);
+    if (d.epi == FDN_EPI_RES) a |= reinterpret_cast<uintptr_t>(d.res);
+    if (d.stats_out) a |= reinterpret_cast<uintptr_t>(d.stats_out);
+    return (a & 15) == 0;                          // measured: 172 -> 64 at level 2 10.2 -> 7.0 ms (71 TFLOP/s)
+}
+
 // K <= 128, N >= 2K, single input segment, plain/LN prologue, no muladd epilogue, weights too big for LDS
 bool smallk_stream_ok(const fdn_conv1x1_desc& d) {
     if (d.K > 128 || d.K <= 64 || d.stats_out || d.kseg[1] > 0) return false;
@@ -1230,6 +1437,12 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         const int nch = (d.K + KC - 1) / KC;
         if (d.pro == FDN_PRO_LN) return nch == 3 ? launch_smallk_stream<3, FDN_PRO_LN>(d, s) : launch_smallk_stream<4, FDN_PRO_LN>(d, s);
         return nch == 3 ? launch_smallk_stream<3, FDN_PRO_NONE>(d, s) : launch_smallk_stream<4, FDN_PRO_NONE>(d, s);
+    }
+    if (kstream_vec_ok(d)) {
+        const int tiles = (d.N + 31) / 32;
+        if (tiles == 1) return launch_kstream_vec<1>(d, s);
+        if (tiles == 2) return launch_kstream_vec<2>(d, s);
+        return launch_kstream_vec<3>(d, s);
     }
     if (narrow_vec_ok(d)) {
         if (d.K <= KC) return launch_smallk_vec<1, FDN_PRO_NONE, 2, true>(d, s);
