@@ -450,6 +450,24 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
         constexpr int U = 8;
         const float2* in2 = reinterpret_cast<const float2*>(in + row0 * W);      // row s, element m at in2[s * M + m]
         const int tot = rpb * M, live = nrow * M;
+        if (M % 2 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {        // 16-byte lanes: two complex inputs per load
+            const float4* in4 = reinterpret_cast<const float4*>(in2);
+            float4* A4 = reinterpret_cast<float4*>(A);
+            const int tot4 = tot / 2, live4 = live / 2;
+            for (int base = threadIdx.x; base < tot4; base += NT * 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + NT * u;
+                    v[u] = in4[idx < live4 ? idx : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + NT * u;
+                    if (idx < tot4) A4[idx] = idx < live4 ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        } else
         for (int base = threadIdx.x; base < tot; base += NT * U) {
             float2 v[U];
 #pragma unroll
@@ -576,6 +594,31 @@ __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict
         const float2* res2 = res ? reinterpret_cast<const float2*>(res + row0 * W) : nullptr;
         float2* out2 = reinterpret_cast<float2*>(out + row0 * W);
         const int live = nrow * M;
+        if (M % 2 == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res)) & 15) == 0) {   // 16-byte lanes
+            const float4* res4 = reinterpret_cast<const float4*>(res2);
+            float4* out4 = reinterpret_cast<float4*>(out2);
+            const float4* Z4 = reinterpret_cast<const float4*>(Z);
+            const int live4 = live / 2;
+            for (int base = threadIdx.x; base < live4; base += NT * 4) {
+                float4 r[4];
+                if (res4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r[u] = res4[min(base + NT * u, live4 - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + NT * u;
+                    if (idx >= live4) continue;
+                    float4 v = Z4[idx];
+                    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+                    if (res4) {
+                        v.x = fmaf(alpha, r[u].x, v.x); v.y = fmaf(alpha, r[u].y, v.y);
+                        v.z = fmaf(alpha, r[u].z, v.z); v.w = fmaf(alpha, r[u].w, v.w);
+                    }
+                    out4[idx] = v;
+                }
+            }
+        } else
         for (int base = threadIdx.x; base < live; base += NT * US) {
             float2 r[US];
             if (res2) {
