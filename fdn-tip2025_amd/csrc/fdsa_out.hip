@@ -179,6 +179,161 @@ __global__ __launch_bounds__(NW * 64, SH <= 19 ? 2 : 1) void fdsa_out_kernel(FoA
 
 int g_cus = 0;
 
+// 8-byte-lane form for level 1 (E <= 38, N <= 32, P % 4 == 0): a lane owns two consecutive pixels, so every load / store
+// moves 8 bytes per lane (the dword form stops at ~3.2 TB/s).  To stay within two waves per SIMD the three LayerNorm
+// groups are taken one after the other - v_value stays in registers, out_g is loaded (the next group while this one is
+// normalised and multiplied), its statistics come from registers (two-pass), and its slice of project_out accumulates
+// into the same two MFMA chains.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 bload2(rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return f32x2{__uint_as_float(u.x), __uint_as_float(u.y)};
+}
+__device__ __forceinline__ void bstore2(f32x2 v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, voff, soff, 0);
+}
+
+template <int SH>
+__global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int E2 = 2 * SH;
+    constexpr int WS = 33;
+    float* tg = smem;                      // gamma [3][E2]
+    float* tb = smem + 3 * E2;             // beta  [3][E2]
+    float* Wl = smem + 6 * E2;             // [3][E2][WS]
+    const int E = a.E, N = a.N;
+    const unsigned P = (unsigned)a.P, P4 = P * 4u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+
+    for (int i = tid; i < 3 * E2; i += NW * 64) {
+        const int g = i / E2, e = i - g * E2;
+        tg[i] = e < E ? a.gamma[g * E + e] : 0.f;
+        tb[i] = e < E ? a.beta[g * E + e] : 0.f;
+    }
+    for (int idx = tid; idx < 3 * E2 * 32; idx += NW * 64) {
+        const int k = idx % (3 * E2), n = idx / (3 * E2);
+        const int g = k / E2, e = k - g * E2;
+        Wl[k * WS + n] = (n < N && e < E) ? a.w[(long)n * 3 * E + g * E + e] : 0.f;
+    }
+    __syncthreads();
+    const float invE = 1.0f / (float)E;
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int b = tile / a.tiles_per_img;
+        const unsigned p_ = (unsigned)(tile - b * a.tiles_per_img) * (NW * 64) + (wave * 32 + ln) * 2;
+        const bool ok = p_ < P;                               // P % 2 == 0: a pixel pair is inside or outside as a whole
+        const unsigned pix = ok ? p_ : P - 2;
+        const float* ob = a.o + (long)b * 4 * E * P;
+        const rsrc_t rg[3] = {mk_rsrc(ob, (unsigned)E * P4), mk_rsrc(ob + (long)E * P, (unsigned)E * P4),
+                              mk_rsrc(ob + (long)2 * E * P, (unsigned)E * P4)};
+        const rsrc_t rv = mk_rsrc(ob + (long)3 * E * P, (unsigned)E * P4);
+        const unsigned voff = (kh * P + pix) * 4u;           // channel e = 2s + kh; e >= E reads 0 (outside the descriptor)
+
+        f32x2 vv[SH], oa[SH], ob2[SH];
+#pragma unroll
+        for (int s = 0; s < SH; ++s) {
+            vv[s] = bload2(rv, voff, (unsigned)(2 * s) * P4);
+            oa[s] = bload2(rg[0], voff, (unsigned)(2 * s) * P4);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            f32x2 (&cur)[SH] = (g & 1) ? ob2 : oa;
+            f32x2 (&nxt)[SH] = (g & 1) ? oa : ob2;
+            if (g < 2) {
+#pragma unroll
+                for (int s = 0; s < SH; ++s) nxt[s] = bload2(rg[g + 1], voff, (unsigned)(2 * s) * P4);
+            }
+            // LayerNorm statistics of this group from registers (two-pass; lanes l and l^32 split the channels)
+            f32x2 m = 0.f;
+#pragma unroll
+            for (int s = 0; s < SH; ++s) m += cur[s];
+            m.x = (m.x + __shfl_xor(m.x, 32)) * invE;
+            m.y = (m.y + __shfl_xor(m.y, 32)) * invE;
+            f32x2 q = 0.f;
+#pragma unroll
+            for (int s = 0; s < SH; ++s) {
+                const f32x2 dl = cur[s] - m;
+                q += (2 * s + kh < E) ? dl * dl : f32x2(0.f);
+            }
+            f32x2 rs;
+            rs.x = 1.0f / sqrtf((q.x + __shfl_xor(q.x, 32)) * invE + 1e-5f);
+            rs.y = 1.0f / sqrtf((q.y + __shfl_xor(q.y, 32)) * invE + 1e-5f);
+#pragma unroll
+            for (int s = 0; s < SH; ++s) {
+                asm volatile("" ::: "memory");                              // table reads stay here (registers)
+                const int e = 2 * s + kh;
+                cur[s] = ((cur[s] - m) * rs * tg[g * E2 + e] + tb[g * E2 + e]) * vv[s];      // norm_g(out_g) * v_value  :633-638
+            }
+#pragma unroll
+            for (int s = 0; s < SH; ++s) {
+                const float wa = Wl[(g * E2 + 2 * s + kh) * WS + ln];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, cur[s].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, cur[s].y, acc[1], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: residual (one batch), store, next LayerNorm's statistics -------------------------------------
+        const unsigned nb4 = (unsigned)N * P4;
+        const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
+        const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
+        const unsigned vo = ok ? (4u * kh * P + pix) * 4u : 0x80000000u;
+        f32x2 rres[16], outv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rres[r] = bload2(rr, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * P4);      // 0 without a residual
+        f32x2 sm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nrow = (r & 3) + 8 * (r >> 2);
+            f32x2 o = f32x2{acc[0][r], acc[1][r]} + rres[r];
+            bstore2(o, ro, vo, (unsigned)nrow * P4);
+            outv[r] = (nrow + 4 * kh < N) ? o : f32x2(0.f);
+            sm += outv[r];
+        }
+        if (a.stats_out) {
+            f32x2 mean, sq = 0.f, rstd;
+            mean.x = (sm.x + __shfl_xor(sm.x, 32)) / (float)N;
+            mean.y = (sm.y + __shfl_xor(sm.y, 32)) / (float)N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x2 dl = outv[r] - mean;
+                sq += ((r & 3) + 8 * (r >> 2) + 4 * kh < N) ? dl * dl : f32x2(0.f);
+            }
+            rstd.x = 1.0f / sqrtf((sq.x + __shfl_xor(sq.x, 32)) / (float)N + 1e-5f);
+            rstd.y = 1.0f / sqrtf((sq.y + __shfl_xor(sq.y, 32)) / (float)N + 1e-5f);
+            if (kh == 0) {
+                const rsrc_t rs_ = mk_rsrc(a.stats_out + (long)b * 2 * P, 2u * P4);
+                const unsigned vs = ok ? pix * 4u : 0x80000000u;
+                bstore2(mean, rs_, vs, 0u);
+                bstore2(rstd, rs_, vs, P4);
+            }
+        }
+    }
+}
+
+int g_cus_v = 0;
+template <int SH>
+int launch_vec(FoArgs a, hipStream_t s) {
+    const size_t lds = (6UL * 2 * SH + 3UL * 2 * SH * 33) * sizeof(float);
+    if (g_cus_v == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
+        g_cus_v = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    a.tiles_per_img = cdiv(a.P, NW * 64);
+    a.total_tiles = a.B * a.tiles_per_img;
+    int grid = g_cus_v * 2;
+    if (grid > a.total_tiles) grid = a.total_tiles;
+    hipLaunchKernelGGL(fdsa_out_vec_kernel<SH>, dim3(grid), dim3(NW * 64), lds, s, a);
+    return fdn_launch_status();
+}
+
 template <int SH, int MT>
 int launch(FoArgs a, hipStream_t s) {
     const size_t lds = (6UL * 2 * SH + 3UL * 2 * SH * (MT * 32 + 1)) * sizeof(float);
@@ -217,6 +372,10 @@ extern "C" int fdn_fdsa_out(const float* o, const float* w, const float* gamma3,
     a.tiles_per_img = a.total_tiles = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int sh = (E + 1) / 2, mt = (N + 31) / 32;
+    if (sh <= 19 && mt == 1 && P % 4 == 0 && getenv("FDN_FO_NOVEC") == nullptr &&
+        ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |
+          reinterpret_cast<uintptr_t>(stats_out)) & 15) == 0)
+        return launch_vec<19>(a, s);                             // level 1, 8-byte lanes
     if (sh <= 19 && mt == 1) return launch<19, 1>(a, s);       // level 1: E = 38, C = 32
     if (sh <= 38 && mt <= 2) return launch<38, 2>(a, s);       // level 2: E = 76, C = 64 (one wave per SIMD, 490 registers: 1.74 vs 1.88 ms)
     return FDN_ERR_UNSUPPORTED;                                  // caller falls back to stats + conv1x1
