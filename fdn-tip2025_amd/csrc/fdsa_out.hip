@@ -194,11 +194,13 @@ __device__ __forceinline__ void bstore2(f32x2 v, rsrc_t r, unsigned voff, unsign
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, voff, soff, 0);
 }
 
-template <int SH>
+// DB: prefetch the next group into a second register set (level 1); without it the other wave on the SIMD covers the
+// load latency (level 2: 76-channel groups, two 32-row tiles - a second set would not leave two waves per SIMD).
+template <int SH, int MT, bool DB>
 __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int E2 = 2 * SH;
-    constexpr int WS = 33;
+    constexpr int WS = MT * 32 + 1;
     float* tg = smem;                      // gamma [3][E2]
     float* tb = smem + 3 * E2;             // beta  [3][E2]
     float* Wl = smem + 6 * E2;             // [3][E2][WS]
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
         tg[i] = e < E ? a.gamma[g * E + e] : 0.f;
         tb[i] = e < E ? a.beta[g * E + e] : 0.f;
     }
-    for (int idx = tid; idx < 3 * E2 * 32; idx += NW * 64) {
+    for (int idx = tid; idx < 3 * E2 * MT * 32; idx += NW * 64) {
         const int k = idx % (3 * E2), n = idx / (3 * E2);
         const int g = k / E2, e = k - g * E2;
         Wl[k * WS + n] = (n < N && e < E) ? a.w[(long)n * 3 * E + g * E + e] : 0.f;
@@ -230,23 +232,25 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
         const rsrc_t rv = mk_rsrc(ob + (long)3 * E * P, (unsigned)E * P4);
         const unsigned voff = (kh * P + pix) * 4u;           // channel e = 2s + kh; e >= E reads 0 (outside the descriptor)
 
-        f32x2 vv[SH], oa[SH], ob2[SH];
+        f32x2 vv[SH], oa[SH], ob2[DB ? SH : 1];
 #pragma unroll
         for (int s = 0; s < SH; ++s) {
             vv[s] = bload2(rv, voff, (unsigned)(2 * s) * P4);
             oa[s] = bload2(rg[0], voff, (unsigned)(2 * s) * P4);
         }
-        f32x16 acc[2];
+        f32x16 acc[MT][2];
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][v][r] = 0.f;
 
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            f32x2 (&cur)[SH] = (g & 1) ? ob2 : oa;
-            f32x2 (&nxt)[SH] = (g & 1) ? oa : ob2;
-            if (g < 2) {
+            f32x2* cur = (DB && (g & 1)) ? ob2 : oa;
+            if (DB && g < 2) {
+                f32x2* nxt = (g & 1) ? oa : ob2;
 #pragma unroll
                 for (int s = 0; s < SH; ++s) nxt[s] = bload2(rg[g + 1], voff, (unsigned)(2 * s) * P4);
             }
@@ -273,9 +277,16 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             }
 #pragma unroll
             for (int s = 0; s < SH; ++s) {
-                const float wa = Wl[(g * E2 + 2 * s + kh) * WS + ln];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, cur[s].x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, cur[s].y, acc[1], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float wa = Wl[(g * E2 + 2 * s + kh) * WS + mt * 32 + ln];
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, cur[s].x, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, cur[s].y, acc[mt][1], 0, 0, 0);
+                }
+            }
+            if (!DB && g < 2) {
+#pragma unroll
+                for (int s = 0; s < SH; ++s) oa[s] = bload2(rg[g + 1], voff, (unsigned)(2 * s) * P4);
             }
         }
         // ---- epilogue: residual (one batch), store, next LayerNorm's statistics -------------------------------------
@@ -283,27 +294,34 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
         const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
         const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
         const unsigned vo = ok ? (4u * kh * P + pix) * 4u : 0x80000000u;
-        f32x2 rres[16], outv[16];
+        f32x2 rres[MT][16], outv[MT][16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rres[r] = bload2(rr, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * P4);      // 0 without a residual
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rres[mt][r] = bload2(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4);      // 0 without a residual
         f32x2 sm = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int nrow = (r & 3) + 8 * (r >> 2);
-            f32x2 o = f32x2{acc[0][r], acc[1][r]} + rres[r];
-            bstore2(o, ro, vo, (unsigned)nrow * P4);
-            outv[r] = (nrow + 4 * kh < N) ? o : f32x2(0.f);
-            sm += outv[r];
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = mt * 32 + (r & 3) + 8 * (r >> 2);
+                f32x2 o = f32x2{acc[mt][0][r], acc[mt][1][r]} + rres[mt][r];
+                bstore2(o, ro, vo, (unsigned)nrow * P4);
+                outv[mt][r] = (nrow + 4 * kh < N) ? o : f32x2(0.f);
+                sm += outv[mt][r];
+            }
         if (a.stats_out) {
             f32x2 mean, sq = 0.f, rstd;
             mean.x = (sm.x + __shfl_xor(sm.x, 32)) / (float)N;
             mean.y = (sm.y + __shfl_xor(sm.y, 32)) / (float)N;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const f32x2 dl = outv[r] - mean;
-                sq += ((r & 3) + 8 * (r >> 2) + 4 * kh < N) ? dl * dl : f32x2(0.f);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 dl = outv[mt][r] - mean;
+                    sq += (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < N) ? dl * dl : f32x2(0.f);
+                }
             rstd.x = 1.0f / sqrtf((sq.x + __shfl_xor(sq.x, 32)) / (float)N + 1e-5f);
             rstd.y = 1.0f / sqrtf((sq.y + __shfl_xor(sq.y, 32)) / (float)N + 1e-5f);
             if (kh == 0) {
@@ -317,9 +335,15 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
 }
 
 int g_cus_v = 0;
-template <int SH>
+template <int SH, int MT, bool DB>
 int launch_vec(FoArgs a, hipStream_t s) {
-    const size_t lds = (6UL * 2 * SH + 3UL * 2 * SH * 33) * sizeof(float);
+    const size_t lds = (6UL * 2 * SH + 3UL * 2 * SH * (MT * 32 + 1)) * sizeof(float);
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fdsa_out_vec_kernel<SH, MT, DB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return FDN_ERR_LAUNCH;
+        attr = true;
+    }
     if (g_cus_v == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -330,7 +354,7 @@ int launch_vec(FoArgs a, hipStream_t s) {
     a.total_tiles = a.B * a.tiles_per_img;
     int grid = g_cus_v * 2;
     if (grid > a.total_tiles) grid = a.total_tiles;
-    hipLaunchKernelGGL(fdsa_out_vec_kernel<SH>, dim3(grid), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((fdsa_out_vec_kernel<SH, MT, DB>), dim3(grid), dim3(NW * 64), lds, s, a);
     return fdn_launch_status();
 }
 
@@ -372,10 +396,11 @@ extern "C" int fdn_fdsa_out(const float* o, const float* w, const float* gamma3,
     a.tiles_per_img = a.total_tiles = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int sh = (E + 1) / 2, mt = (N + 31) / 32;
-    if (sh <= 19 && mt == 1 && P % 4 == 0 && getenv("FDN_FO_NOVEC") == nullptr &&
+    const bool vec_ok = P % 4 == 0 && getenv("FDN_FO_NOVEC") == nullptr &&
         ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |
-          reinterpret_cast<uintptr_t>(stats_out)) & 15) == 0)
-        return launch_vec<19>(a, s);                             // level 1, 8-byte lanes
+          reinterpret_cast<uintptr_t>(stats_out)) & 15) == 0;
+    if (vec_ok && sh <= 19 && mt == 1) return launch_vec<19, 1, true>(a, s);       // level 1, 8-byte lanes
+    if (vec_ok && sh <= 38 && mt <= 2 && getenv("FDN_FO_NOVEC2") == nullptr) return launch_vec<38, 2, false>(a, s);       // level 2
     if (sh <= 19 && mt == 1) return launch<19, 1>(a, s);       // level 1: E = 38, C = 32
     if (sh <= 38 && mt <= 2) return launch<38, 2>(a, s);       // level 2: E = 76, C = 64 (one wave per SIMD, 490 registers: 1.74 vs 1.88 ms)
     return FDN_ERR_UNSUPPORTED;                                  // caller falls back to stats + conv1x1
