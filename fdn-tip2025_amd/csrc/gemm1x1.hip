@@ -23,11 +23,33 @@
 // MFMAs issue.  Prologues (LayerNorm, 3xLayerNorm * v_value, LayerNorm * x1 + x1) are applied in
 // registers between the load and the MFMA.
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
 constexpr int KC = 32;     // K chunk (16 MFMA k-steps)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// The activation / epilogue kind are wave-uniform runtime values of the descriptor.  Tested per element they cost a chain
+// of scalar compare-and-branch per output value (the switch of apply_act alone is ~8 branches: 5.3k of a 23.5k-cycle output
+// tile of the level-3 to_hidden conv went there, tools/gemm_trace2.py).  Each kernel therefore writes its epilogue once as a
+// generic lambda over two integral constants and picks the copy once per tile.
+template <int V> using IC = std::integral_constant<int, V>;
+#define FDN_EPI_MODES(act_c, epi_c)                                                                     \
+    const int act_ = decltype(act_c)::value ? d.act : (int)FDN_ACT_NONE;                                \
+    const int epi_ = decltype(epi_c)::value >= 0 ? (int)decltype(epi_c)::value : d.epi;
+#define FDN_EPI_DISPATCH(f)                                                                             \
+    do {                                                                                                \
+        if (d.act != FDN_ACT_NONE) f(IC<1>(), IC<-1>());                                                \
+        else if (d.epi == FDN_EPI_NONE) f(IC<0>(), IC<FDN_EPI_NONE>());                                 \
+        else if (d.epi == FDN_EPI_RES) f(IC<0>(), IC<FDN_EPI_RES>());                                   \
+        else f(IC<0>(), IC<FDN_EPI_MULADD>());                                                          \
+    } while (0)
+#define FDN_ACT_DISPATCH(f)                                                                             \
+    do {                                                                                                \
+        if (d.act != FDN_ACT_NONE) f(IC<1>(), IC<-1>());                                                \
+        else f(IC<0>(), IC<-1>());                                                                      \
+    } while (0)
 
 struct Geo {
     int tiles_per_img;     // pixel tiles (NW*32 px) per image
@@ -262,6 +284,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && !EARLY) ? ((MT <= 2 && PRO == 
                     // (tools/gemm_trace.py)
                     // batch size by register budget: MT = 1 lives on 128 registers (2 workgroups per CU); the wide LN3_GATE
                     // kernels sit at 256 already and keep the one-by-one form
+                    // (this kernel keeps the runtime tests of d.act / d.epi per element: resolved per tile as in the other kernels, the
+                    // freer schedule spills 33-110 registers at MT >= 4 and K = 345 -> 128 went from 0.56 to 0.96 ms)
                     constexpr int EB = MT == 1 ? 4 : 16;
                     if constexpr (EB == 1) {
 #pragma unroll
@@ -492,6 +516,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_kernel(fdn_conv1x1_des
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             mfma_chain<NCH * 16>(acc, Wl + kh * NS + m * 32 + ln, 2 * NS, xa);
+            auto epilogue = [&](auto act_c, auto epi_c) __attribute__((always_inline)) {
+                FDN_EPI_MODES(act_c, epi_c)
             if (cur.ok) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -499,12 +525,14 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_kernel(fdn_conv1x1_des
                     const unsigned soff = (unsigned)nrow * P4;
                     float v = acc[r];
                     v += bl[nrow + 4 * kh];
-                    v = apply_act(v, d.act);
-                    if (d.epi == FDN_EPI_RES) v += bload(rr, voff, soff);
-                    else if (d.epi == FDN_EPI_MULADD) v = v * bload(rm, voff, soff) + bload(rd, voff, soff);
+                    v = apply_act(v, act_);
+                    if (epi_ == FDN_EPI_RES) v += bload(rr, voff, soff);
+                    else if (epi_ == FDN_EPI_MULADD) v = v * bload(rm, voff, soff) + bload(rd, voff, soff);
                     bstore(v, ro, voff, soff);
                 }
             }
+            };
+            FDN_EPI_DISPATCH(epilogue);
         }
         cur = nxt; tile = ntile; live = nlive;
     }
@@ -634,6 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
 #pragma unroll
                     for (int i = 0; i < 8; ++i) a[(grp + 1) & 1][i] = w[((grp + 1) * 8 + i) * 2 * NS];
                 }
+                __builtin_amdgcn_sched_barrier(0);      // (reads stay one group ahead of their use, see conv1x1_smallk_stream_vec_kernel)
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -644,6 +673,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                     for (int i = 0; i < 8; ++i) xa[grp * 8 + i] = bloadv<VEC>(rn, voffn, (unsigned)(2 * (grp * 8 + i)) * P4);
                 }
             }
+            auto epilogue = [&](auto act_c, auto epi_c) __attribute__((always_inline)) {
+                FDN_EPI_MODES(act_c, epi_c)
             if constexpr (!TAIL) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -653,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                     for (int v = 0; v < VEC; ++v) o[v] = acc[v][r];
                     o += bl[nrow + 4 * kh];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
+                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], act_);
                     bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);        // rows >= N fall outside the descriptor
                 }
             } else {
@@ -661,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                 // the channel-LayerNorm statistics of the result (two-pass, registers only; lanes l and l^32 hold
                 // complementary rows of the same pixels)
                 vf rres[16], outv[16];
-                if (d.epi == FDN_EPI_RES) {
+                if (epi_ == FDN_EPI_RES) {
                     const rsrc_t rr = mk_rsrc(d.res + (long)cur.b * d.rbs, (unsigned)N * P4);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) rres[r] = bloadv<VEC>(rr, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * P4);
@@ -675,8 +706,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                     for (int v = 0; v < VEC; ++v) o[v] = acc[v][r];
                     o += bl[nrow + 4 * kh];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
-                    if (d.epi == FDN_EPI_RES) o += rres[r];
+                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], act_);
+                    if (epi_ == FDN_EPI_RES) o += rres[r];
                     bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);
                     outv[r] = (nrow + 4 * kh < N) ? o : vf(0.f);
                     sm += outv[r];
@@ -701,6 +732,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                     }
                 }
             }
+            };
+            if constexpr (TAIL) FDN_EPI_DISPATCH(epilogue); else FDN_ACT_DISPATCH(epilogue);
         }
         cur = nxt; tile = ntile; live = nlive;
     }
@@ -806,6 +839,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_stream_kernel(fdn_conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             mfma_chain<NCH * 16>(acc, Wl + (wstep & 1) * (Kp * WS) + kh * WS + ln, 2 * WS, xa);
+            auto epilogue = [&](auto act_c, auto epi_c) __attribute__((always_inline)) {
+                FDN_EPI_MODES(act_c, epi_c)
             if (cur.ok) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -813,11 +848,13 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_smallk_stream_kernel(fdn_conv
                     const unsigned soff = (unsigned)nrow * P4;
                     float v = acc[r];
                     v += bl[nrow + 4 * kh];
-                    v = apply_act(v, d.act);
-                    if (d.epi == FDN_EPI_RES) v += bload(rr, voff, soff);
+                    v = apply_act(v, act_);
+                    if (epi_ == FDN_EPI_RES) v += bload(rr, voff, soff);
                     bstore(v, ro, voff, soff);
                 }
             }
+            };
+            FDN_EPI_DISPATCH(epilogue);
             if (more) w_stash((wstep + 1) & 1);
             __syncthreads();
         }
@@ -937,6 +974,8 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
 #pragma unroll
                     for (int i = 0; i < 8; ++i) a[(grp + 1) & 1][i] = w[((grp + 1) * 8 + i) * 2 * WS];
                 }
+                __builtin_amdgcn_sched_barrier(0);      // the reads stay a whole group (16 MFMAs) ahead of their use: left alone the
+                                                        // scheduler sinks them next to it and the LDS latency stalls the matrix pipe
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -947,6 +986,9 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
                     for (int i = 0; i < 8; ++i) xa[grp * 8 + i] = bloadv<VEC>(rn, voffn, (unsigned)(2 * (grp * 8 + i)) * P4);
                 }
             }
+            auto epilogue = [&](auto act_c, auto epi_c) __attribute__((always_inline)) {
+                FDN_EPI_MODES(act_c, epi_c)
+                (void)epi_;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
@@ -955,9 +997,11 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
                 for (int v = 0; v < VEC; ++v) o[v] = acc[v][r];
                 o += bl[nrow + 4 * kh];
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
+                for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], act_);
                 bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);
             }
+            };
+            FDN_ACT_DISPATCH(epilogue);
             if (more) w_stash((wstep + 1) & 1);
             __syncthreads();
         }
@@ -1062,10 +1106,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kstream_vec_kernel(fdn_conv1x1
             const rsrc_t rr = mk_rsrc(d.res ? d.res + (long)cur.b * d.rbs : d.out, d.res ? nb4 : 0u);
             const unsigned voff = cur.ok ? (4u * kh * P + cur.pix) * 4u : 0x80000000u;
             vf sm = 0.f;
+            auto epilogue = [&](auto act_c, auto epi_c) __attribute__((always_inline)) {
+                FDN_EPI_MODES(act_c, epi_c)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 vf l0[16];                                              // residual of one 32-channel tile as a batch
-                if (d.epi == FDN_EPI_RES) {
+                if (epi_ == FDN_EPI_RES) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) l0[r] = bloadv<VEC>(rr, voff, (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * P4);
                 }
@@ -1077,8 +1123,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kstream_vec_kernel(fdn_conv1x1
                     for (int v = 0; v < VEC; ++v) o[v] = acc[m][v][r];
                     o += bl[nrow + 4 * kh];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], d.act);
-                    if (d.epi == FDN_EPI_RES) o += l0[r];
+                    for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], act_);
+                    if (epi_ == FDN_EPI_RES) o += l0[r];
                     bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);
                     o = (nrow + 4 * kh < N) ? o : vf(0.f);
 #pragma unroll
@@ -1087,6 +1133,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kstream_vec_kernel(fdn_conv1x1
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            };
+            if constexpr (MT <= 2) FDN_ACT_DISPATCH(epilogue); else epilogue(IC<1>(), IC<-1>());      // (MT = 3 spills 41 registers with the activation resolved)
             if (d.stats_out) {
                 vf mean, sq = 0.f, rstd;
 #pragma unroll
