@@ -396,11 +396,12 @@ extern "C" int fdn_fdsa_out(const float* o, const float* w, const float* gamma3,
     a.tiles_per_img = a.total_tiles = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int sh = (E + 1) / 2, mt = (N + 31) / 32;
-    const bool vec_ok = P % 4 == 0 && getenv("FDN_FO_NOVEC") == nullptr &&
+    static const bool novec = getenv("FDN_FO_NOVEC") != nullptr, novec2 = getenv("FDN_FO_NOVEC2") != nullptr;      // A/B switches
+    const bool vec_ok = P % 4 == 0 && !novec &&
         ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |
           reinterpret_cast<uintptr_t>(stats_out)) & 15) == 0;
     if (vec_ok && sh <= 19 && mt == 1) return launch_vec<19, 1, true>(a, s);       // level 1, 8-byte lanes
-    if (vec_ok && sh <= 38 && mt <= 2 && getenv("FDN_FO_NOVEC2") == nullptr) return launch_vec<38, 2, false>(a, s);       // level 2
+    if (vec_ok && sh <= 38 && mt <= 2 && !novec2) return launch_vec<38, 2, false>(a, s);       // level 2
     if (sh <= 19 && mt == 1) return launch<19, 1>(a, s);       // level 1: E = 38, C = 32
     if (sh <= 38 && mt <= 2) return launch<38, 2>(a, s);       // level 2: E = 76, C = 64 (one wave per SIMD, 490 registers: 1.74 vs 1.88 ms)
     return FDN_ERR_UNSUPPORTED;                                  // caller falls back to stats + conv1x1

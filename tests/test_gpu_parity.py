@@ -448,6 +448,11 @@ def test_conv1x1_baseline_shapes_all_forms(A, K, N, H, W):
     xn = xn * g.double().view(1, -1, 1, 1) + be.double().view(1, -1, 1, 1)
     ref_ln = torch.einsum("nk,bkhw->bnhw", w.double(), xn)
     assert rel_rms(ops.conv1x1(xd, wd, ln=(ops.chan_stats(xd), dev(g), dev(be))).cpu(), ref_ln) < 2e-6
+    # the activation copies of the epilogues (resolved once per tile, separate code from the plain copy): act before res
+    lk = torch.nn.functional.leaky_relu(ref + b.double().view(1, -1, 1, 1), 0.1)
+    assert rel_rms(ops.conv1x1(xd, wd, dev(b), act=1).cpu(), lk) < 1e-6
+    assert rel_rms(ops.conv1x1(xd, wd, dev(b), act=1, res=dev(res)).cpu(), lk + res.double()) < 1e-6
+    assert rel_rms(ops.conv1x1(xd, wd, act=3, ln=(ops.chan_stats(xd), dev(g), dev(be))).cpu(), torch.sigmoid(ref_ln)) < 2e-6
     got = ops.conv1x1(xd, wd, res=dev(res), want_stats=N <= 160)
     tot = ref + res.double()
     assert rel_rms(got.cpu(), tot) < 1e-6
