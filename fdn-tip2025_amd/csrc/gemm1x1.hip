@@ -651,6 +651,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
             for (int v = 0; v < VEC; ++v)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+            // TAIL: the residual of this tile is requested before the MFMA groups, so its latency hides behind them (after
+            // them it was the one exposed round trip of every tile)
+            vf rres[TAIL ? 16 : 1];
+            if (TAIL && d.epi == FDN_EPI_RES) {
+                const rsrc_t rr = mk_rsrc(d.res + (long)cur.b * d.rbs, (unsigned)N * P4);
+#pragma unroll
+                for (int r = 0; r < (TAIL ? 16 : 1); ++r) rres[r] = bloadv<VEC>(rr, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * P4);
+            }
             // A operands one group of 8 k-steps ahead (as mfma_chain); each feeds VEC MFMAs
             const float* w = Wl + kh * NS + m * 32 + ln;
             float a[2][8];
@@ -691,12 +699,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                 // TAIL (N <= 32, the narrow project_out convs): residual as one batch of vector loads, then the stores and
                 // the channel-LayerNorm statistics of the result (two-pass, registers only; lanes l and l^32 hold
                 // complementary rows of the same pixels)
-                vf rres[16], outv[16];
-                if (epi_ == FDN_EPI_RES) {
-                    const rsrc_t rr = mk_rsrc(d.res + (long)cur.b * d.rbs, (unsigned)N * P4);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rres[r] = bloadv<VEC>(rr, voff, (unsigned)((r & 3) + 8 * (r >> 2)) * P4);
-                }
+                vf outv[16];                    // (rres: requested ahead of the MFMA groups, below)
                 vf sm = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
