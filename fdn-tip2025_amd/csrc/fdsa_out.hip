@@ -238,6 +238,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             vv[s] = bload2(rv, voff, (unsigned)(2 * s) * P4);
             oa[s] = bload2(rg[0], voff, (unsigned)(2 * s) * P4);
         }
+        const unsigned nb4 = (unsigned)N * P4;
+        const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
+        const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
+        const unsigned vo = ok ? (4u * kh * P + pix) * 4u : 0x80000000u;
+        f32x2 rres[MT][16];
         f32x16 acc[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -275,6 +280,15 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
                 const int e = 2 * s + kh;
                 cur[s] = ((cur[s] - m) * rs * tg[g * E2 + e] + tb[g * E2 + e]) * vv[s];      // norm_g(out_g) * v_value  :633-638
             }
+            if (DB && g == 2) {      // (level 2 has no idle set: requested ahead it spills 39 registers, so it stays in the epilogue there)
+                // the residual is requested here: v_value (and, with DB, the idle register set) is dead from this point, and the
+                // round trip hides behind the last group's MFMAs instead of standing alone in the epilogue
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rres[mt][r] = bload2(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4);      // 0 without a residual
+            }
 #pragma unroll
             for (int s = 0; s < SH; ++s) {
 #pragma unroll
@@ -290,16 +304,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             }
         }
         // ---- epilogue: residual (one batch), store, next LayerNorm's statistics -------------------------------------
-        const unsigned nb4 = (unsigned)N * P4;
-        const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
-        const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
-        const unsigned vo = ok ? (4u * kh * P + pix) * 4u : 0x80000000u;
-        f32x2 rres[MT][16], outv[MT][16];
+        f32x2 outv[MT][16];
+        if (!DB) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                rres[mt][r] = bload2(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4);      // 0 without a residual
+                for (int r = 0; r < 16; ++r)
+                    rres[mt][r] = bload2(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4);      // 0 without a residual
+        }
         f32x2 sm = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
