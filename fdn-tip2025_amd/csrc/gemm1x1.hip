@@ -941,7 +941,15 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
         stats_issue(cur);
     }
     int wstep = 0;
+#ifdef FDN_GEMM_TRACE   // tools/gemm_trace2.py: s_memtime stamps per output tile (waves 0 and 4 of workgroup 0) into d.mul (vec4 = 12345)
+    unsigned long long* trc2 = (d.vec4 == 12345 && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+                                   ? reinterpret_cast<unsigned long long*>(const_cast<float*>(d.mul)) + (wave ? 1024 : 0) : nullptr;
+#define TR2(i) if (trc2 && wstep < 120) trc2[wstep * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define TR2(i)
+#endif
     while (live) {
+        TR2(6)
         if (PRO != FDN_PRO_NONE) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -961,6 +969,7 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
             const int mnext = (m + 1 < ntiles) ? m + 1 : 0;
             const bool more = (m + 1 < ntiles) || nlive;
             const bool refill = nlive && m == ntiles - 1;
+            TR2(0)
             if (more) w_fetch(mnext);                              // next weight tile: L2 -> registers
             f32x16 acc[VEC];
 #pragma unroll
@@ -989,6 +998,7 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
                     for (int i = 0; i < 8; ++i) xa[grp * 8 + i] = bloadv<VEC>(rn, voffn, (unsigned)(2 * (grp * 8 + i)) * P4);
                 }
             }
+            TR2(1)
             auto epilogue = [&](auto act_c, auto epi_c) __attribute__((always_inline)) {
                 FDN_EPI_MODES(act_c, epi_c)
                 (void)epi_;
@@ -1005,8 +1015,11 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
             }
             };
             FDN_ACT_DISPATCH(epilogue);
+            TR2(2)
             if (more) w_stash((wstep + 1) & 1);
+            TR2(3)
             __syncthreads();
+            TR2(4)
         }
         cur = nxt; tile = ntile; live = nlive;
     }
