@@ -34,13 +34,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case FDN_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;   // LeakyReLU(0.1), FDN_arch.py:28
-        case FDN_ACT_RELU: return v > 0.f ? v : 0.f;
-        case FDN_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-        case FDN_ACT_GELU: return gelu_erf(v);
-        default: return v;
-    }
+    // act is wave-uniform: every test below is a scalar compare-and-branch PER VALUE, so the common kinds come first (the
+    // switch form walked ~8 branches even for FDN_ACT_NONE).  Kernels with long epilogues resolve act once per tile instead.
+    if (act == FDN_ACT_NONE) return v;
+    if (act <= FDN_ACT_RELU) return v > 0.f ? v : (act == FDN_ACT_LEAKY ? 0.1f * v : 0.f);   // LeakyReLU(0.1) FDN_arch.py:28 / ReLU
+    return act == FDN_ACT_SIGMOID ? 1.0f / (1.0f + expf(-v)) : gelu_erf(v);
 }
 
 // sin and cos together, ~1 ulp for |x| < 8192 (three-constant Cody-Waite reduction by pi/2, then the classic
