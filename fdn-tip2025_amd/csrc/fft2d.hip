@@ -828,7 +828,11 @@ int set_lds(K kernel, size_t bytes) {
 }
 
 int pick_rpb(int M) {
-    int rpb = (int)((48 * 1024) / (2L * M * sizeof(float2)));
+    // rows per workgroup from an LDS budget for the ping-pong buffers.  Swept on the B=8 720p forward (row kernels, ms per
+    // step r2c / c2r): 16 KiB 16.6 / 15.0, 24 KiB 13.3 / 13.4, 32 KiB 13.3 / 12.0, 40 KiB 14.0 / 13.4, 48 KiB 14.1 / 13.4,
+    // 64 KiB 15.4 / 14.5 - the passes are latency bound, so workgroups per CU count for more than rows per workgroup
+    // (M = 640: 3 rows, 41 KiB with the tables, 3 workgroups per CU, 480 radix-4 jobs for 256 threads)
+    int rpb = (int)((32 * 1024) / (2L * M * sizeof(float2)));
     if (rpb > 8) rpb = 8;
     if (rpb < 1) rpb = 1;
     return rpb;
