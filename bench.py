@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """FDN inference bench on MI355X:  images/s of the whole LPNet -> FDN forward (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process spawns one rank per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (the driver's launch; WORLD_SIZE must equal --gpus)
 
 A step = one pass of the hot path over one batch: config 2 of BASELINE.json, 8 synthetic images of
-1280x720 reflect-padded to 736x1280, fp32, already resident in HBM.  N GPUs = N independent shards
-of 8 images (the batch shards embarrassingly) -> "scaling": "weak"; no data-path
-collective unless --scatter-gather puts the RCCL scatter/gather of north_star in the timed region.
-Weights are deterministic synthetic (the trained FDN checkpoint is absent from the reference
-checkout); LPNet uses the real LPNet_lolblur weights when tests/golden has them.
+1280x720 reflect-padded to 736x1280, fp32, already resident in HBM.  N GPUs = N shards of 8 images
+(the batch shards embarrassingly) -> "scaling": "weak".  With N > 1 the global batch lives
+on rank 0 and the timed region contains the RCCL scatter of the inputs and gather of the outputs that
+north_star names (BASELINE.json configs[3] at N = 8: 64 images, 8 x 8); the same K steps without the
+collectives are reported beside it ("without_collectives").  --dtype bf16 --height 1080 --width 1920
+--batch 4 is configs[2].  Weights are deterministic synthetic (the trained FDN checkpoint is absent from
+the reference checkout); LPNet uses the real LPNet_lolblur weights when tests/golden has them.
 
-Extra JSON objects: "roofline" for the dominant kernel family (timed live with HIP events on the
-launch stream in one instrumented forward), "cpu_baseline" (the CPU oracle on a bounded sample).
+Extra JSON objects: "roofline" = the dominant INDIVIDUAL kernel (entry point at one shape = one rocprof
+kernel) against its own bound, timed live with HIP events on the launch stream in an instrumented
+single-stream forward; "top_kernels" = the three largest, each against its own bound; "cpu_baseline" =
+the CPU oracle on a bounded sample.
 """
 import argparse
 import ctypes
@@ -63,18 +67,94 @@ def make_input(batch, h, w, dev, seed):
     return torch.nn.functional.pad(x, (0, wn, 0, hn), mode="reflect").to(dev).contiguous()   # inference_fdn_lolblur.py:60-62
 
 
+def _iv(v):
+    """ctypes argument -> Python int (plain ints pass through, c_long / c_int carry .value)."""
+    return v.value if hasattr(v, "value") else v
+
+
+def describe_call(name, a):
+    """(group key, algorithmic FLOPs, algorithmic HBM bytes) of one C-ABI call: the figures of DESIGN.md section 4 (each
+    operand read once, each result written once, fp32), conv FLOPs only (FFT / pointwise work is not counted)."""
+    f = b = 0.0
+    key = name
+    if name == "fdn_conv1x1":
+        d = a[0]._obj
+        f = 2.0 * d.B * d.K * d.N * d.P
+        b = 4.0 * d.B * d.P * (d.K + d.N + (d.N if d.epi == 1 else 0) + (2 * d.N if d.epi == 2 else 0)
+                               + (d.K // 3 if d.pro == 2 else 0) + (d.K if d.pro == 3 else 0))
+        key = f"fdn_conv1x1[{d.K}->{d.N},pro{d.pro},epi{d.epi},P={d.P}]"
+    elif name == "fdn_fdsa_fused":
+        B, C, E, H, W = (_iv(v) for v in a[8:13])
+        f, b = 2.0 * B * H * W * C * 4 * E, 4.0 * B * H * W * (C + 4 * E)
+        key = f"fdn_fdsa_fused[C={C},E={E},{H}x{W}]"
+    elif name == "fdn_fdffn_fused":
+        B, C, Hd, H, W = (_iv(v) for v in a[10:15])
+        f, b = 2.0 * B * H * W * C * Hd, 4.0 * B * H * W * (C + Hd)
+        key = f"fdn_fdffn_fused[C={C},Hd={Hd},{H}x{W}]"
+    elif name == "fdn_fdsa_core":
+        B, E, H, W = (_iv(v) for v in a[4:8])
+        b = 4.0 * B * H * W * 8 * E
+        key = f"fdn_fdsa_core[E={E},{H}x{W}]"
+    elif name == "fdn_fdsa_out":
+        B, E, N, P = (_iv(v) for v in a[7:11])
+        f, b = 2.0 * B * P * 3 * E * N, 4.0 * B * P * (4 * E + 2 * N)
+        key = f"fdn_fdsa_out[E={E},N={N},P={P}]"
+    elif name == "fdn_fdffn_mid":
+        B, Hd, H, W = (_iv(v) for v in a[6:10])
+        b = 4.0 * B * H * W * 2 * Hd
+        key = f"fdn_fdffn_mid[Hd={Hd},{H}x{W}]"
+    elif name == "fdn_dwconv_gate":
+        B, C, H, W = (_iv(v) for v in a[3:7])
+        b = 4.0 * B * H * W * 2 * C
+        key = f"fdn_dwconv_gate[C={C},{H}x{W}]"
+    elif name == "fdn_ffn_tail":
+        B, C, N, H, W = (_iv(v) for v in a[6:11])
+        f, b = 2.0 * B * H * W * C * N, 4.0 * B * H * W * (C + 2 * N)
+        key = f"fdn_ffn_tail[{C}->{N},{H}x{W}]"
+    elif name == "fdn_rfft_rows":
+        rows, W = _iv(a[2]), _iv(a[3])
+        b = 4.0 * rows * (W + 2 * (W // 2 + 1))
+        key = f"fdn_rfft_rows[W={W},rows={rows}]"
+    elif name == "fdn_irfft_rows":
+        planes, H, W = _iv(a[4]), _iv(a[5]), _iv(a[6])
+        b = 4.0 * planes * H * (2 * (W // 2 + 1) + W + (W if a[8] is not None and _iv(a[8]) else 0))
+        key = f"fdn_irfft_rows[{H}x{W},planes={planes}]"
+    elif name == "fdn_fft_cols_fcaffn":
+        B, C, H, Wf = (_iv(v) for v in a[4:8])
+        b = 4.0 * B * H * Wf * (4 * C + 8)
+        key = f"fdn_fft_cols_fcaffn[C={C},{H}x{Wf}]"
+    elif name == "fdn_conv2d":
+        B, Cin, H, W, Cout, KH, KW, st, pad = (_iv(v) for v in a[5:14])
+        OH, OW = (H + 2 * pad - KH) // st + 1, (W + 2 * pad - KW) // st + 1
+        f = 2.0 * B * OH * OW * Cin * Cout * KH * KW
+        b = 4.0 * B * (Cin * H * W + Cout * OH * OW * (2 if a[3] is not None and _iv(a[3]) else 1))
+        key = f"fdn_conv2d[{Cin}->{Cout},k{KH}s{st},{H}x{W}]"
+    elif name == "fdn_chan_stats":
+        B, G, E, P = (_iv(v) for v in a[3:7])
+        b = 4.0 * B * P * (G * E + 2 * G)
+        key = f"fdn_chan_stats[G={G},E={E},P={P}]"
+    elif name == "fdn_layernorm_chan":
+        B, C, P = (_iv(v) for v in a[4:7])
+        b = 4.0 * B * P * 2 * C
+        key = f"fdn_layernorm_chan[C={C},P={P}]"
+    elif name == "fdn_img_mod_maps":
+        B, C, H, W = (_iv(v) for v in a[7:11])
+        b = 4.0 * B * H * W * (3 + 2 * C)
+        key = f"fdn_img_mod_maps[C={C},{H}x{W}]"
+    return key, f, b
+
+
 class KernelTimer:
-    """Wrap every C-ABI entry point with HIP events on the launch stream (one instrumented forward)."""
+    """Wrap every C-ABI entry point with HIP events on the launch stream (one instrumented single-stream forward).
+    Calls are grouped per entry point AND shape: at a fixed shape an entry point always launches the same kernel
+    instantiation, so a group is one individual rocprof kernel."""
 
     def __init__(self):
         import fdn_hip
         self.lib = fdn_hip.lib()
         self.records = []
-        self.names = [n for n in ("fdn_conv1x1", "fdn_fdsa_out", "fdn_ffn_tail", "fdn_chan_stats", "fdn_layernorm_chan", "fdn_fdsa_core", "fdn_fdffn_mid",
-                                  "fdn_dwconv_gate", "fdn_dwconv3x3", "fdn_img_mod_maps", "fdn_rfft_rows", "fdn_irfft_rows",
-                                  "fdn_fft_cols_fcaffn", "fdn_fft_cols_fwd", "fdn_fft_cols_inv_polar", "fdn_conv2d",
-                                  "fdn_conv_transpose4x4s2", "fdn_resample", "fdn_dw1x1_pad1", "fdn_avgpool3s2",
-                                  "fdn_global_avgpool", "fdn_se_apply", "fdn_scale_batch", "fdn_gamma_curve")]
+        decl = [ln.split("(")[0].split()[-1] for ln in open(os.path.join(ROOT, "include", "fdn_hip.h")) if ln.startswith("int fdn_")]
+        self.names = [n for n in decl if n not in ("fdn_abi_version", "fdn_fft_prepare")]
         self.orig = {}
 
     def __enter__(self):
@@ -87,13 +167,7 @@ class KernelTimer:
                 e0.record()
                 r = _f(*a)
                 e1.record()
-                flops = byts = 0
-                if _n == "fdn_conv1x1":
-                    d = a[0]._obj
-                    flops = 2.0 * d.B * d.K * d.N * d.P
-                    byts = 4.0 * d.B * d.P * (d.K + d.N + (d.N if d.epi == 1 else 0) + (2 * d.N if d.epi == 2 else 0)
-                                              + (d.K // 3 if d.pro == 2 else 0) + (d.K if d.pro == 3 else 0))
-                self.records.append((_n, e0, e1, flops, byts))
+                self.records.append((_n, e0, e1) + describe_call(_n, a))
                 return r
             setattr(self.lib, n, wrapped)
         return self
@@ -103,31 +177,47 @@ class KernelTimer:
             setattr(self.lib, n, f)
 
     def summary(self):
+        """{group key: [entry point, launches, ms, flops, bytes]}"""
         torch.cuda.synchronize()
         agg = {}
-        for n, e0, e1, fl, by in self.records:
-            t = agg.setdefault(n, [0, 0.0, 0.0, 0.0])
-            t[0] += 1
-            t[1] += e0.elapsed_time(e1)
-            t[2] += fl
-            t[3] += by
+        for n, e0, e1, key, fl, by in self.records:
+            t = agg.setdefault(key, [n, 0, 0.0, 0.0, 0.0])
+            t[1] += 1
+            t[2] += e0.elapsed_time(e1)
+            t[3] += fl
+            t[4] += by
         return agg
 
 
-def pmc_traffic_per_launch(prefix):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (profiles/*traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB * 1024; FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for coalesced streaming reads on gfx950).  None when no profile is committed."""
+def kernel_roofline(key, rec, traffic):
+    """One individual kernel against its OWN bound: the larger of (algorithmic bytes / 8 TB/s) and (conv FLOPs /
+    157.3 TFLOP/s) decides whether it is priced against HBM or the fp32 matrix cores."""
+    n, cnt, ms, fl, by = rec
+    t = ms * 1e-3
+    t_hbm, t_mfma = by / (PEAK_HBM_GBS * 1e9), fl / (PEAK_F32_MFMA_TF * 1e12)
+    out = {"kernel": key, "launches": cnt, "avg_ms": ms / cnt}
+    if t_mfma > t_hbm:
+        ach = fl / t / 1e12
+        out.update({"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TF})
+    elif by > 0:
+        ach = by / t / 1e9
+        out.update({"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS})
+    else:
+        out.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
+    out["algorithmic_bytes_per_launch"] = by / cnt if by else None
+    out["traffic"] = traffic.get(key) if traffic else None
+    return out
+
+
+def pmc_traffic_by_group():
+    """HBM bytes per launch of each kernel group from the committed rocprofv3 PMC passes (the newest
+    profiles/*traffic_groups.json, written by tools/pmc_groups.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs over one
+    launch of each group, corrected per load form as that file documents).  {} when no profile is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_groups.json")))
     if not files:
-        return None
-    d = json.load(open(files[-1]))["kernels"]
-    n = sum(v["launches"] for k, v in d.items() if k.startswith(prefix))
-    if n == 0:
-        return None
-    gb = sum(2.0 * v["fetch_GB_raw"] + v["write_GB"] for k, v in d.items() if k.startswith(prefix))
-    return gb * 1e9 / n
+        return {}
+    return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(files[-1]))["groups"].items()}
 
 
 def usable_cores():
@@ -147,7 +237,10 @@ def usable_cores():
 
 
 def cpu_baseline(h=256, w=256):
-    """Oracle (fp32, PyTorch CPU ops) on ONE h x w image; reported in 736x1280-equivalent images/s."""
+    """The CPU oracle (fp32, PyTorch CPU ops = a port of the reference's algorithm) on ONE h x w image: BASELINE.json
+    configs[0] as it stands (`value_config0`), and scaled by pixel count to the 736x1280 unit of the metric (`value`).
+    The scaling flatters the CPU: the reference itself measured 0.0028 images/s at 736x1280 on 8 threads
+    because its working set leaves the caches - a bounded sample cannot show that."""
     import fdn_oracle as O
     from weights import synth_state_dict
     from common import fdn_shapes, lpnet_weights
@@ -162,8 +255,41 @@ def cpu_baseline(h=256, w=256):
         O.fdn_forward(P, x, r)
         dt = time.perf_counter() - t0
     px_ratio = (h * w) / (736.0 * 1280.0)
-    return {"value": px_ratio / dt, "unit": "images/s (736x1280-equivalent)", "cores": cores, "kind": "port",
-            "sample": f"1 image {h}x{w} fp32, LPNet+FDN oracle forward, {dt:.2f} s wall, scaled by pixel count"}
+    return {"value": px_ratio / dt, "unit": "images/s (736x1280-equivalent, scaled by pixel count from the sample)", "cores": cores,
+            "kind": "port", "value_config0": 1.0 / dt, "unit_config0": f"images/s at {h}x{w} (BASELINE.json configs[0], unscaled)",
+            "sample": f"1 image {h}x{w} fp32, LPNet+FDN oracle forward, {dt:.2f} s wall"}
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this process never touches a GPU; it starts one child per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, exactly what torch.distributed.run would set) and
+    returns the worst exit code.  Rank 0's JSON line goes to our stdout."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+            if rc:
+                break
+    finally:
+        for p in procs:                        # a failed rank must not leave the others waiting in a collective
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    return rc
 
 
 def main():
@@ -171,117 +297,173 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-GPU batch is split over (measured best: 3)")
-    ap.add_argument("--scatter-gather", action="store_true", help="time RCCL scatter of inputs / gather of outputs too")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 = BASELINE.json configs[1] (the reference's arithmetic); bf16 = configs[2]: bf16 STORAGE of the "
+                         "block-internal activations between kernels, fp32 math / FFT / residual stream (DESIGN.md)")
+    ap.add_argument("--scatter-gather", dest="sg", action="store_true", default=None,
+                    help="put the RCCL scatter of the inputs / gather of the outputs in the timed region (default: on when N > 1)")
+    ap.add_argument("--no-scatter-gather", dest="sg", action="store_false")
     ap.add_argument("--variant", choices=("lolblur", "lolv1"), default="lolblur",
                     help="lolblur = FDN (BASELINE.json's metric); lolv1 = FDN_lolv1, dim 24 (SURVEY.md 8(f) rank 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU / gloo rehearsal of the launcher, sharding, scatter / gather and timing protocol with a stand-in "
+                         "forward (tests/test_multirank_cpu.py); measures nothing")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))       # parent: no GPU call before or after this line
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU: the FDN path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {a.gpus}: the two must agree")
+
+    from fdn_hip import sharding
     dist = None
+    if a.dry_run:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU: the FDN path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("FDN_BENCH_FORCE_DIST") == "1":      # (the env switch exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if a.dry_run:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+    sg = (world > 1) if a.sg is None else a.sg
+    sg = sg and dist is not None
 
-    from fdn_hip.pipeline import forward_streams
-    net, lp = build_models(dev, a.variant)
-    x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
+    if a.dry_run:
+        x = torch.rand(a.batch, 3, 16, 24, generator=torch.Generator().manual_seed(1000 + rank))
+        mk = lambda r: torch.rand(a.batch, 3, 16, 24, generator=torch.Generator().manual_seed(1000 + r))
+        forward = lambda t: t * 2.0 + 1.0
+        sync = lambda: None
+    else:
+        from fdn_hip.pipeline import forward_streams
+        import fdn_hip
+        fdn_hip.set_storage_dtype(a.dtype)
+        net, lp = build_models(dev, a.variant)
+        x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
+        mk = lambda r: make_input(a.batch, a.height, a.width, dev, seed=1000 + r)
+        forward = lambda t: forward_streams(net, lp, t, a.streams)     # LPNet -> FDN, sub-batches on separate HIP streams
+        sync = torch.cuda.synchronize
     B, _, H, W = x.shape
     root_in = root_out = None
-    if a.scatter_gather and dist is not None and rank == 0:
-        root_in = [make_input(a.batch, a.height, a.width, dev, seed=1000 + r) for r in range(world)]
+    if sg and rank == 0:
+        root_in = [mk(r) for r in range(world)]                        # the global batch lives on the root: N x B images
         root_out = [torch.empty_like(x) for _ in range(world)]
 
-    def step():
-        xin = x
-        if a.scatter_gather and dist is not None:
-            xin = torch.empty_like(x)
-            dist.scatter(xin, root_in if rank == 0 else None, src=0)
-        out = forward_streams(net, lp, xin, a.streams)          # LPNet -> FDN, batch halves on separate HIP streams
-        if a.scatter_gather and dist is not None:
-            dist.gather(out, root_out if rank == 0 else None, dst=0)
-        return out
-
-    for _ in range(a.warmup):
-        step()
+    def step(with_sg):
+        if with_sg:
+            return sharding.sharded_step(dist, forward, x, root_in, root_out)
+        return forward(x)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(a.steps):
-        step()
-    e1.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    dt = max(wall, e0.elapsed_time(e1) / 1e3)
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(with_sg, steps):
+        barrier()
+        t0 = time.perf_counter()
+        if not a.dry_run:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for _ in range(steps):
+            step(with_sg)
+        if not a.dry_run:
+            e1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        if not a.dry_run:
+            dt = max(dt, e0.elapsed_time(e1) / 1e3)
+        return sharding.max_over_ranks(dist, dt, dev) if dist is not None else dt
 
-    roof = None
-    if rank == 0 and not a.no_roofline:
+    for _ in range(a.warmup):
+        step(sg)
+    dt = timed(sg, a.steps)                                            # THE measurement: exactly K steps
+    dt_nosg = None
+    if sg:                                                             # beside it: the same K steps without the collectives
+        dt_nosg = timed(False, a.steps)
+    if a.dry_run and sg and rank == 0:                                 # the rehearsal also checks the plumbing
+        ok = all(torch.equal(o, forward(i)) for o, i in zip(root_out, root_in))
+        assert ok, "dry run: gathered outputs differ from the root's own forward"
+
+    roof = top = entries = None
+    if rank == 0 and not a.no_roofline and not a.dry_run:
         agg = None
         for _ in range(2):                                          # the first instrumented pass also pays one-off host costs
             with KernelTimer() as kt:
                 with torch.no_grad():
                     net(x, ratio_i=lp(x), device=dev)               # single stream: events bracket each launch
             cur = kt.summary()
-            agg = cur if agg is None else {k: (v if v[1] <= agg.get(k, v)[1] else agg[k]) for k, v in cur.items()}
-        total_ms = sum(v[1] for v in agg.values())
-        dom = max(agg.items(), key=lambda kv: kv[1][1])
-        name, (cnt, ms, fl, by) = dom
-        if name == "fdn_conv1x1":
-            ach = fl / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TF,
-                    "traffic": pmc_traffic_per_launch("conv1x1"), "kernel": "conv1x1_kernel (fdn_conv1x1)", "launches": cnt, "avg_ms": ms / cnt,
-                    "hbm_gbs_algorithmic": by / (ms * 1e-3) / 1e9, "share_of_step": ms / total_ms}
-        else:
-            roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                    "kernel": name, "launches": cnt, "avg_ms": ms / cnt, "share_of_step": ms / total_ms}
-        roof["by_kernel_ms"] = {k: round(v[1], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+            agg = cur if agg is None else {k: (v if v[2] <= agg.get(k, v)[2] else agg[k]) for k, v in cur.items()}
+        total_ms = sum(v[2] for v in agg.values())
+        traffic = pmc_traffic_by_group()
+        ranked = sorted(agg.items(), key=lambda kv: -kv[1][2])
+        top = []
+        for key, rec in ranked[:3]:
+            r_ = kernel_roofline(key, rec, traffic)
+            r_["share_of_step"] = rec[2] / total_ms
+            top.append(r_)
+        roof = dict(top[0])                                         # the dominant INDIVIDUAL kernel
+        entries = {}
+        for key, rec in agg.items():
+            entries[rec[0]] = entries.get(rec[0], 0.0) + rec[2]
+        roof["single_stream_forward_ms"] = total_ms
+        roof["by_entry_point_ms"] = {k: round(v, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1])}
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.dry_run:
         cpu = cpu_baseline()
 
     if rank == 0:
         imgs = world * B * a.steps
         ips = imgs / dt
         P = H * W
+        headline = a.variant == "lolblur" and (a.height, a.width, B) == (720, 1280, 8) and a.dtype == "f32"
+        cfg3 = a.variant == "lolblur" and (a.height, a.width, B) == (1080, 1920, 4) and a.dtype == "bf16"
+        if a.dry_run:
+            metric, workload = "DRY RUN (CPU/gloo rehearsal, measures nothing)", "dry run"
+        elif a.variant == "lolblur":
+            metric = f"images/sec, FDN (LPNet->FDN forward) {a.width}x{a.height} bs={B} {'fp32' if a.dtype == 'f32' else 'bf16-storage'}"
+            workload = (("BASELINE.json configs[1]: " if headline else "BASELINE.json configs[2]: " if cfg3 else "")
+                        + f"FDN {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU "
+                        + ("fp32" if a.dtype == "f32" else "bf16 storage of block-internal activations, fp32 math"))
+            if world > 1 and headline:
+                workload += f"; BASELINE.json configs[3] shape: global batch {world * B} sharded {world} ways"
+        else:
+            metric = f"images/sec, FDN_lolv1 (LPNet->FDN_lolv1 forward) {a.width}x{a.height} bs={B} fp32 [not the headline metric]"
+            workload = f"FDN_lolv1 (dim 24) {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU fp32"
         line = {
-            "metric": ("images/sec, FDN (LPNet->FDN forward) 1280x720 bs=8 fp32" if a.variant == "lolblur" else
-                       f"images/sec, FDN_lolv1 (LPNet->FDN_lolv1 forward) {a.width}x{a.height} bs={B} fp32 [not the headline metric]"),
-            "value": ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": metric, "value": ips, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "ms_per_image": 1e3 / ips * world, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[1]: FDN {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU fp32" if a.variant == "lolblur"
-                                    else f"FDN_lolv1 (dim 24) {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU fp32"),
-                       "global_batch": world * B, "parallelism": f"batch-shard x{world}", "weights": "synthetic (tamed 0.03) FDN + real LPNet",
-                       "scatter_gather_timed": bool(a.scatter_gather), "hip_streams": a.streams},
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
+                       "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1},
             "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * 4.0 * P * (ips / world) / (PEAK_HBM_GBS * 1e9),
                            "mfma_f32_frac": F_ALG_PER_PX * P * (ips / world) / (PEAK_F32_MFMA_TF * 1e12)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "top_kernels": top, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        if dt_nosg is not None:
+            line["without_collectives"] = {"value": imgs / dt_nosg, "ms_per_step": dt_nosg / a.steps * 1e3,
+                                           "note": "the same K steps with every rank's shard already resident (no scatter / gather)"}
+        if a.dry_run:
+            line["dry_run"] = True
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -25,20 +25,7 @@ from fdn_hip import ACT_LEAKY, ACT_NONE, ACT_SIGMOID, ops
 # ---------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------
-class _Cache:
-    """Derived weight tensors (concatenated / folded), rebuilt when a source parameter changes."""
-
-    def __init__(self):
-        self._store = {}
-
-    def get(self, name, srcs, build):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in srcs)
-        hit = self._store.get(name)
-        if hit is None or hit[0] != key:
-            with torch.no_grad():
-                hit = (key, build().contiguous())
-            self._store[name] = hit
-        return hit[1]
+_Cache = ops.WeightCache          # derived weights live on their module (stream-safe, see fdn_hip/ops.py)
 
 
 def _w(p):
@@ -93,8 +80,14 @@ class FDSA(nn.Module):
 
     def fused(self, x, ln=None, res=None):
         e = self.expand_dim
-        hidden = ops.conv1x1(x, _w(self.to_hidden.weight), ln=ln)
-        o = ops.fdsa_core(hidden, _w(self.to_hidden_dw.weight), _w(self.fft))
+        if x.shape[1] in ops.FDSA_FUSED_C:      # levels 1-2: LayerNorm + to_hidden + core in one launch, no hidden tensor in HBM
+            srcs = [self.to_hidden.weight] + ([ln[1], ln[2]] if ln is not None else [])
+            wpk, bpk = self._c.get("pk" if ln is not None else "pk0", srcs, lambda: ops.fdsa_pack(
+                _w(self.to_hidden.weight), *((ln[1], ln[2]) if ln is not None else (None, None))))
+            o = ops.fdsa_fused(x, ln[0] if ln is not None else None, wpk, bpk, _w(self.to_hidden_dw.weight), _w(self.fft))
+        else:
+            hidden = ops.conv1x1(x, _w(self.to_hidden.weight), ln=ln, cache=(self._c, "th"))
+            o = ops.fdsa_core(hidden, _w(self.to_hidden_dw.weight), _w(self.fft))
         norms = (self.norm1, self.norm2, self.norm3)
         gam = self._c.get("g", [n.body.weight for n in norms], lambda: torch.cat([n.body.weight.detach() for n in norms]))
         bet = self._c.get("b", [n.body.bias for n in norms], lambda: torch.cat([n.body.bias.detach() for n in norms]))
@@ -126,9 +119,10 @@ class FDFFN(nn.Module):
         self.dwconv = nn.Conv2d(hidden, hidden * 2, kernel_size=3, padding=1, groups=hidden, bias=bias)
         self.project_in = nn.Conv2d(dim, hidden, kernel_size=1, bias=bias)
         self.project_out = nn.Conv2d(hidden, dim, kernel_size=1, bias=bias)
+        self._c = _Cache()
 
     def fused(self, x, ln=None, res=None):
-        h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln)
+        h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln, cache=(self._c, "pi"))
         y = ops.fdffn_mid(h, _w(self.space[0].weight), _w(self.space[2].weight), _w(self.ffta), _w(self.fftp))
         return ops.ffn_tail(y, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None)
 

@@ -10,16 +10,19 @@ mkdir -p fdn_hip "$BUILD"
 # VALU-issue-bound kernels listed here measure faster without it (fdffn_mid 2.35 -> 1.89 ms at level 1).
 NOSLP="patchfft"
 OBJS=""
+PIDS=""
 for f in csrc/*.hip; do
   n=$(basename "${f%.hip}")
   o=$BUILD/$n.o
   fl=""
   for k in $NOSLP; do [ "$k" = "$n" ] && fl="-fno-slp-vectorize"; done
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ csrc/common.hpp -nt "$o" ] || [ ../include/fdn_hip.h -nt "$o" ] || [ build.sh -nt "$o" ]; then
+    rm -f "$o"                      # a failed compile must not leave a stale object for the link below
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $fl $EXTRA -c "$f" -o "$o" &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
-wait
+for p in $PIDS; do wait "$p" || { echo "build.sh: a hipcc job failed" >&2; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS
 echo "built $OUT"

@@ -528,6 +528,259 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// FDSA front half in ONE launch: channel LayerNorm + to_hidden (1x1 conv on the matrix cores) + everything
+// fdsa_core_kernel does (FDN_arch.py:575-632) - the 4E-channel hidden tensor never exists in HBM.
+//
+// Workgroup = one 8 x 32 pixel tile (1 x 4 patches) of one image, ALL E channels, 256 threads.
+//   * the normalised input strip of the 10 x 34 halo tile (C channels) is loaded once and lives in registers as the
+//     B operand of v_mfma_f32_32x32x2_f32 (pixels on the lane axis, exactly like conv1x1_smallk_kernel): 11 strips of
+//     32 halo pixels, three (waves 0-2) or two (wave 3) per wave, C/2 VGPRs each;
+//   * channels are walked in chunks of 8: the 32 MFMA rows of a chunk are (q,k,v,v_value) x 8 channels (weights
+//     packed per chunk / k-step / lane by fdn_fdsa_pack, LayerNorm affine folded in), each wave runs C/2 MFMAs per
+//     strip and parks the 32 x 32 result in the LDS hidden tile (zero outside the image = the conv's zero padding);
+//   * then thread = (channel of the chunk, patch, row): stencil -> row rfft -> LDS spectra -> column phase
+//     (160 threads) -> inverse rows -> 32-byte stores, the code of fdsa_core_kernel.
+// HBM traffic: C planes in (+26 % halo, mostly L2 hits: each XCD owns a contiguous run of tiles), 4E planes out.
+// ------------------------------------------------------------------------------------------
+constexpr int FT_H = 8, FT_W = 32;
+constexpr int FHW = FT_W + 2, FHH = FT_H + 2;      // halo tile 10 x 34
+constexpr int FHP = FHH * FHW;                     // 340 halo pixels
+constexpr int FNS = (FHP + 31) / 32;               // 11 strips of 32 pixels
+constexpr int FRS = 35;                            // LDS row stride of a hidden plane: (35 r + 8 px) mod 32 distinct for r < 8, px < 4
+constexpr int FPL = FHH * FRS;                     // floats per plane
+constexpr int FEG = 8;                             // channels per chunk (x 4 kinds = 32 MFMA rows)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FusedArgs {
+    const float* x;
+    long xbs;
+    const float* stats;
+    const float* wpk;
+    const float* bpk;
+    const float* dww;
+    const float* fftw;
+    float* out;
+    int E, H, W, tiles_x, tiles_per_img, nchunks;
+};
+
+template <int C, bool LN>
+__global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
+    __shared__ float hid[32 * FPL + 4];
+    __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+    int t_ = blockIdx.x;
+    {   // blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous run of tiles
+        const int n = gridDim.x;
+        if ((n & 7) == 0) t_ = (t_ & 7) * (n >> 3) + (t_ >> 3);
+    }
+    const int b = t_ / a.tiles_per_img, ti = t_ - b * a.tiles_per_img;
+    const int ty0 = (ti / a.tiles_x) * FT_H, tx0 = (ti % a.tiles_x) * FT_W;
+    const int E = a.E, H = a.H, W = a.W;
+    const unsigned P = (unsigned)H * W, hw4 = P * 4u;
+    const rsrc_t rx = mk_rsrc(a.x + (long)b * a.xbs, (unsigned)C * hw4);
+    const rsrc_t rst = mk_rsrc(LN ? a.stats + (long)b * 2 * P : a.x, LN ? 2u * hw4 : 0u);
+    const rsrc_t rout = mk_rsrc(a.out + (long)b * 4 * E * P, 4u * E * hw4);
+
+    // ---- the wave's strips of the normalised halo tile: B operands, resident for the whole workgroup ----------
+    float xs[3][C / 2];
+    int pixoff[3];
+    bool pvalid[3];
+#pragma unroll
+    for (int si = 0; si < 3; ++si) {
+        const int s = wave + 4 * si;
+        const int p = s * 32 + ln;
+        const int r = p / FHW, c = p - r * FHW;
+        const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+        const bool in_tile = s < FNS && p < FHP;
+        const bool ok = in_tile && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        pvalid[si] = ok;
+        pixoff[si] = in_tile ? r * FRS + c : 32 * FPL;            // spare cells behind the planes
+        const unsigned g = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
+        float mu = 0.f, rs = 1.f;
+        if (LN) {
+            mu = bload(rst, g, 0);
+            rs = bload(rst, g, hw4);
+        }
+#pragma unroll
+        for (int j = 0; j < C / 2; ++j) xs[si][j] = bload(rx, g + (unsigned)kh * hw4, (unsigned)(2 * j) * hw4);
+        if (LN) {
+#pragma unroll
+            for (int j = 0; j < C / 2; ++j) xs[si][j] = (xs[si][j] - mu) * rs;
+        }
+    }
+
+    // VALU-phase coordinates: lanes 0-31 / 32-63 of a wave take two different channels of the chunk
+    const int el = wave * 2 + kh;
+    const int row = lane & 7, px = (lane >> 3) & 3;
+    const int slot = el * 4 + px;
+    const int gx0 = tx0 + px * 8;
+    const unsigned opix = gx0 < W ? (unsigned)((ty0 + row) * W + gx0) * 4u : OOB;
+    const float* hb = hid + el * FPL + row * FRS + px * 8;
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const int e0 = ch * FEG;
+        const int e = e0 + el;
+        const int ec = e < E ? e : E - 1;
+        // ---- operands of this chunk: packed weights (coalesced), bias of this lane's 16 accumulator rows, stencil taps
+        float aw[C / 2];
+        {
+            const float* wp = a.wpk + ((long)ch * (C / 2)) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < C / 2; ++j) aw[j] = wp[j * 64];
+        }
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = a.bpk[ch * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+        float wk[4][9];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wk[t][i] = a.dww[(long)(t * E + ec) * 9 + i];
+        float fg[8];
+        {
+            const int pjc = tid < NP * 5 ? tid / 5 : 0, kxc = tid < NP * 5 ? tid % 5 : 0;
+            const int eq = e0 + (pjc >> 2);
+            const int eqc = eq < E ? eq : E - 1;
+#pragma unroll
+            for (int ky = 0; ky < 8; ++ky) fg[ky] = a.fftw[(eqc * 8 + ky) * 5 + kxc];
+        }
+
+        // ---- to_hidden on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes ---------------------
+#pragma unroll
+        for (int si = 0; si < 3; ++si) {
+            if (wave + 4 * si < FNS) {                              // wave-uniform
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int j = 0; j < C / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[j], xs[si][j], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;           // row = kind * 8 + channel of the chunk
+                    hid[m * FPL + pixoff[si]] = pvalid[si] ? acc[r] + bv[r] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- rows: depthwise 3x3 (to_hidden_dw, FDN_arch.py:578) + forward row transforms; v_value goes straight out
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float* hp = hb + t * 8 * FPL;
+            float o8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float v[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v[j] = hp[dy * FRS + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) o8[j] = fmaf(wk[t][dy * 3 + dx], v[j + dx], o8[j]);
+            }
+            if (t < 3) {
+                float2 sp[5];
+                rfft8_row(o8, sp);
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * 8 + row] = sp[kx];
+            } else {
+                bstore8(o8, rout, e < E ? opix + (unsigned)(3 * E + e) * hw4 : OOB, 0);
+            }
+        }
+        __syncthreads();
+
+        // ---- columns: thread = (slot, kx): forward, recombine, inverse (as fdsa_core_kernel) ------------------------
+        if (tid < NP * 5) {
+            const int pj = tid / 5, kx = tid - pj * 5;
+            float2 q[8], k[8], v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                q[i] = S[(0 * NP + pj) * PS + kx * 8 + i];
+                k[i] = S[(1 * NP + pj) * PS + kx * 8 + i];
+                v[i] = S[(2 * NP + pj) * PS + kx * 8 + i];
+            }
+            fft8<false>(q);
+            fft8<false>(k);
+            fft8<false>(v);
+            float2 o1[8], o2[8], o3[8];
+#pragma unroll
+            for (int ky = 0; ky < 8; ++ky) {
+                const float f = fg[ky];
+                const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));            // :591-593
+                float2 qk = cmul(q[ky], k[ky]);                                               // :595
+                qk = make_float2(rd1(qk.x), rd1(qk.y));                                       // :597
+                const float qk2 = qk.x * qk.x + qk.y * qk.y, v2 = v1.x * v1.x + v1.y * v1.y;
+                const float qka = qk2 * rsq(qk2);                                             // |qk|  :599
+                const float iv = rsq(v2), va = v2 * iv;                                       // |v|   :601
+                const float2 qr = make_float2(rd1(q[ky].x), rd1(q[ky].y));                    // :603
+                const float2 kr = make_float2(rd1(k[ky].x), rd1(k[ky].y));                    // :604
+                const float nq = rsq(qr.x * qr.x + qr.y * qr.y), nk = rsq(kr.x * kr.x + kr.y * kr.y);
+                float2 u = cmulc(make_float2(qr.x * nq, qr.y * nq), make_float2(kr.x * nk, kr.y * nk));   // :605-607
+                const float g = qka * iv;
+                o1[ky] = make_float2(va * u.x, va * u.y);                                     // :609-612
+                o2[ky] = make_float2(g * v1.x, g * v1.y);                                     // :617-619
+                o3[ky] = make_float2(qka * u.x, qka * u.y);                                   // :627-629
+            }
+            fft8<true>(o1);
+            fft8<true>(o2);
+            fft8<true>(o3);
+            constexpr float sc = 1.0f / 64.0f;   // norm='backward'
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                S[(0 * NP + pj) * PS + kx * 8 + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
+                S[(1 * NP + pj) * PS + kx * 8 + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
+                S[(2 * NP + pj) * PS + kx * 8 + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
+            }
+        }
+        __syncthreads();
+
+        // ---- inverse rows, 32-byte segments straight to global (out1|out2|out3) --------------------------------------
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float2 xk[5];
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) xk[kx] = S[(t * NP + slot) * PS + kx * 8 + row];
+            float r8[8];
+            irfft8_row(xk, r8);
+            bstore8(r8, rout, e < E ? opix + (unsigned)(t * E + e) * hw4 : OOB, 0);
+        }
+        // (the next chunk's MFMA phase writes `hid`, free since the second barrier; its row phase rewrites S behind
+        //  the barrier that follows the MFMA phase, i.e. after every thread has finished these reads)
+    }
+}
+
+// fdn_fdsa_pack: [4E][C] weights (+ LayerNorm gamma / beta of the input) -> per (chunk, k-step, lane) A operands
+__global__ void fdsa_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 float* __restrict__ wpk, float* __restrict__ bpk, int C, int E, int nchunks) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nw = nchunks * (C / 2) * 64;
+    if (idx < nw) {
+        const int lane = idx & 63, j = (idx >> 6) % (C / 2), ch = (idx >> 6) / (C / 2);
+        const int m = lane & 31, k = 2 * j + (lane >> 5);
+        const int e = ch * FEG + (m & 7);
+        float v = 0.f;
+        if (e < E) {
+            v = w[(long)((m >> 3) * E + e) * C + k];
+            if (gamma) v *= gamma[k];
+        }
+        wpk[idx] = v;
+    } else if (idx < nw + nchunks * 32) {
+        const int i = idx - nw, ch = i >> 5, m = i & 31;
+        const int e = ch * FEG + (m & 7);
+        double s = 0.0;
+        if (e < E && beta) {
+            const float* wr = w + (long)((m >> 3) * E + e) * C;
+            for (int k = 0; k < C; ++k) s += (double)wr[k] * (double)beta[k];
+        }
+        bpk[i] = (float)s;
+    }
+}
+
 }  // namespace
 
 extern "C" int fdn_fdsa_core(const float* hidden, const float* dw_w, const float* fft_w, float* out, int B, int E, int H,
@@ -557,5 +810,47 @@ extern "C" int fdn_fdffn_mid(const float* x, const float* w0, const float* w2, c
     // VALU issue, and the float4 stash costs four LDS writes per load)
     hipLaunchKernelGGL(fdffn_mid_kernel<false>, dim3(tx * ty, (Hd + CPB - 1) / CPB, B), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                        w0, w2, ffta, fftp, out, Hd, H, W, tx);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, float* bpk, int C, int E,
+                             fdn_stream_t stream) {
+    FDN_CHECK_ARG(w && wpk && bpk && C > 0 && C % 2 == 0 && E > 0 && (!gamma == !beta));
+    const int nch = (E + FEG - 1) / FEG;
+    const int total = nch * (C / 2) * 64 + nch * 32;
+    hipLaunchKernelGGL(fdsa_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma, beta, wpk,
+                       bpk, C, E, nch);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* bpk, const float* dw_w,
+                              const float* fft_w, float* out, int B, int C, int E, int H, int W, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && wpk && bpk && dw_w && fft_w && out && B > 0 && E > 0 && H > 0 && W > 0);
+    FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0);
+    FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    FDN_CHECK_ARG(16ull * E * H * W < 0x80000000ull && 4ull * C * H * W < 0x80000000ull);   // 32-bit byte offsets per image
+    FusedArgs a;
+    a.x = x; a.xbs = xbs; a.stats = stats; a.wpk = wpk; a.bpk = bpk; a.dww = dw_w; a.fftw = fft_w; a.out = out;
+    a.E = E; a.H = H; a.W = W;
+    a.tiles_x = cdiv(W, FT_W);
+    a.tiles_per_img = a.tiles_x * (H / FT_H);
+    a.nchunks = (E + FEG - 1) / FEG;
+    const long total = (long)B * a.tiles_per_img;
+    FDN_CHECK_ARG(total < 0x7fffffffL);
+    const dim3 grid((unsigned)total), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define FDN_FUSED_CASE(CC)                                                                       \
+    case CC:                                                                                     \
+        if (stats) hipLaunchKernelGGL((fdsa_fused_kernel<CC, true>), grid, block, 0, s, a);      \
+        else hipLaunchKernelGGL((fdsa_fused_kernel<CC, false>), grid, block, 0, s, a);           \
+        break;
+    switch (C) {
+        FDN_FUSED_CASE(24)
+        FDN_FUSED_CASE(32)
+        FDN_FUSED_CASE(48)
+        FDN_FUSED_CASE(64)
+        default: return FDN_ERR_UNSUPPORTED;
+    }
+#undef FDN_FUSED_CASE
     return fdn_launch_status();
 }

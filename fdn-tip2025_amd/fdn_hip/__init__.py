@@ -37,7 +37,7 @@ class FdnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4          # include/fdn_hip.h: bumped on any signature change
+ABI_VERSION = 5          # include/fdn_hip.h: bumped on any signature change
 
 
 def lib_path():
@@ -69,6 +69,24 @@ def check(code, what):
 
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Storage format of the block-internal activations that travel between kernels:
+#   "f32"  - everything fp32, the reference's arithmetic (BASELINE.json configs[1]);
+#   "bf16" - the wide intermediates inside FDSA / FDFFN (out1|out2|out3|v_value, the FDFFN hidden tensors) are STORED as
+#            bf16; every product, accumulation, FFT, LayerNorm statistic and the residual stream stay fp32 (configs[2]).
+_storage = "f32"
+
+
+def set_storage_dtype(name):
+    global _storage
+    if name not in ("f32", "bf16"):
+        raise ValueError(f"storage dtype must be 'f32' or 'bf16', got {name!r}")
+    _storage = name
+
+
+def storage_dtype():
+    return _storage
 
 
 def dev(t, what="tensor"):

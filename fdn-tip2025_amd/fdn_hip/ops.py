@@ -34,33 +34,56 @@ def _flat(t, what):
     return ctypes.c_void_p(t.data_ptr())
 
 
-_folded = {}
+class WeightCache:
+    """Derived weight tensors of ONE module (concatenated / folded / packed operands), rebuilt when a source
+    parameter changes (data pointer or version).  Entries are stream-safe: the building stream records an event and
+    any other stream that later hits the entry waits on it once, so a cold model may be driven from several HIP
+    streams at once (pipeline.forward_streams).  The cache lives on its module: it dies with it."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, name, srcs, build):
+        key = tuple(None if p is None else (p.data_ptr(), p._version, str(p.device)) for p in srcs)
+        hit = self._store.get(name)
+        cuda = any(p is not None and p.is_cuda for p in srcs)
+        cur = torch.cuda.current_stream() if cuda else None
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                val = build()
+            ev = None
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+            hit = (key, val, ev, {cur.cuda_stream} if cuda else set())
+            self._store[name] = hit
+        elif cuda and cur.cuda_stream not in hit[3]:
+            if not torch.cuda.is_current_stream_capturing():       # (a capture is preceded by a synchronising warm-up)
+                cur.wait_event(hit[2])
+                hit[3].add(cur.cuda_stream)
+        return hit[1]
+
+    def versions(self):
+        return tuple(h[0] for h in self._store.values())
+
+    def __deepcopy__(self, memo):          # HIP events do not copy; a copied module rebuilds its derived weights
+        return WeightCache()
 
 
-def _fold_ln(w, bias, gamma, beta):
+def fold_ln(w, bias, gamma, beta):
     """w' = w * diag(gamma), bias' = w @ beta (+ bias): a LayerNorm's affine part in front of a 1x1 conv is linear in the
-    conv, so it is folded once per (weight, gamma, beta) version into the GEMM operands (FDN_PRO_LN then only
-    normalises).  Cached on the parameters' storage pointers and versions."""
-    key = (w.data_ptr(), w._version, gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version,
-           None if bias is None else (bias.data_ptr(), bias._version), str(w.device))
-    hit = _folded.get(key)
-    if hit is None:
-        with torch.no_grad():
-            w2 = w.reshape(w.shape[0], -1)
-            wf = (w2 * gamma.reshape(1, -1)).contiguous()
-            bf = torch.mv(w2.double(), beta.double()).float()
-            if bias is not None:
-                bf = bf + bias
-            # the source tensors are kept alive with the entry: their addresses (the key) cannot be reused while it exists
-            hit = (wf, bf.contiguous(), (w, gamma, beta, bias))
-        if len(_folded) > 1024:
-            _folded.clear()
-        _folded[key] = hit
-    return hit[0], hit[1]
+    conv, so it is folded into the GEMM operands (FDN_PRO_LN then only normalises)."""
+    with torch.no_grad():
+        w2 = w.reshape(w.shape[0], -1)
+        wf = (w2 * gamma.reshape(1, -1)).contiguous()
+        bf = torch.mv(w2.double(), beta.double()).float()
+        if bias is not None:
+            bf = bf + bias
+    return wf, bf.contiguous()
 
 
 def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None, ln_muladd=None, res=None,
-            muladd=None, want_stats=False):
+            muladd=None, want_stats=False, cache=None):
     """1x1 conv with fused prologue/epilogue (fdn_conv1x1).
 
     want_stats: also produce the channel-LayerNorm statistics of the output in the epilogue and attach
@@ -69,6 +92,7 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
     xs: tensor or list of <=3 tensors concatenated along channels.  w: [N, K] or [N, K, 1, 1].
     ln=(stats, gamma, beta) | ln3_gate=(stats, gamma[3E], beta[3E], vv) | ln_muladd=(stats, gamma, beta, x1)
     res: residual added after act | muladd=(mul, add).
+    cache=(WeightCache, name): where the LayerNorm-folded operands of `ln` are kept (else they are rebuilt per call).
     """
     if torch.is_tensor(xs):
         xs = [xs]
@@ -90,7 +114,10 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
     d.pro, d.ln_group = PRO_NONE, K
     if ln is not None:
         d.pro = PRO_LN                        # the kernel normalises only; the affine part rides in the weights
-        w, bias = _fold_ln(w, bias, ln[1], ln[2])
+        if cache is not None:
+            w, bias = cache[0].get(cache[1], [w, bias, ln[1], ln[2]], lambda w=w, bias=bias: fold_ln(w, bias, ln[1], ln[2]))
+        else:
+            w, bias = fold_ln(w, bias, ln[1], ln[2])
         d.w, d.bias = _flat(w, "w"), _flat(bias, "bias")
         d.stats = _flat(ln[0], "stats")
     elif ln3_gate is not None:
@@ -151,6 +178,34 @@ def fdsa_core(hidden, dw_w, fft_w):
     out = torch.empty_like(hidden)
     check(lib().fdn_fdsa_core(_flat(hidden, "hidden"), _flat(dw_w, "dw_w"), _flat(fft_w, "fft_w"), _flat(out, "out"),
                               B, C4 // 4, H, W, stream()), "fdn_fdsa_core")
+    return out
+
+
+FDSA_FUSED_C = (24, 32, 48, 64)          # input widths fdn_fdsa_fused is instantiated for
+
+
+def fdsa_pack(w, gamma, beta):
+    """to_hidden weight [4E, C(,1,1)] (+ the LayerNorm in front) -> MFMA operands of fdn_fdsa_fused (fdn_fdsa_pack)."""
+    E4, C = w.shape[0], w.shape[1]
+    E = E4 // 4
+    nch = (E + 7) // 8
+    wpk = torch.empty((nch, C // 2, 64), device=w.device, dtype=torch.float32)
+    bpk = torch.empty((nch, 32), device=w.device, dtype=torch.float32)
+    check(lib().fdn_fdsa_pack(_flat(w.reshape(E4, C), "w"), _flat(gamma, "gamma"), _flat(beta, "beta"), _flat(wpk, "wpk"),
+                              _flat(bpk, "bpk"), C, E, stream()), "fdn_fdsa_pack")
+    return wpk, bpk
+
+
+def fdsa_fused(x, stats, wpk, bpk, dw_w, fft_w):
+    """LayerNorm + to_hidden + fdsa_core in one launch (fdn_fdsa_fused): x [B,C,H,W] -> (out1|out2|out3|v_value) [B,4E,H,W]."""
+    B, C, H, W = x.shape
+    E = fft_w.shape[0]
+    assert C in FDSA_FUSED_C, C
+    out = torch.empty((B, 4 * E, H, W), device=x.device, dtype=torch.float32)
+    ptr, xbs = _planes(x, "x")
+    check(lib().fdn_fdsa_fused(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), _flat(wpk, "wpk"), _flat(bpk, "bpk"),
+                               _flat(dw_w, "dw_w"), _flat(fft_w, "fft_w"), _flat(out, "out"), B, C, E, H, W, stream()),
+          "fdn_fdsa_fused")
     return out
 
 

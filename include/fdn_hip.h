@@ -91,6 +91,20 @@ int fdn_layernorm_chan(const float* x, const float* gamma, const float* beta, fl
 int fdn_fdsa_core(const float* hidden, const float* dw_w, const float* fft_w, float* out, int B, int E, int H, int W,
                   fdn_stream_t stream);
 
+/* FDSA front half in ONE launch (FDN_arch.py:575-632 + the LayerNorm of :668 in front): channel LayerNorm of x,
+ * to_hidden (1x1 conv C -> 4E on the matrix cores, evaluated on the 1-pixel halo of each 8x32 tile) and everything
+ * fdn_fdsa_core does; the 4E-channel hidden tensor never reaches HBM.
+ * fdn_fdsa_pack: to_hidden weight w [4E][C] (+ optional LayerNorm gamma, beta [C], folded in: w*diag(gamma), w@beta)
+ *   -> wpk [ceil(E/8)][C/2][64] (MFMA A operands per chunk of 8 channels, k-step, lane), bpk [ceil(E/8)][32].
+ * fdn_fdsa_fused: x [B][C][H][W] (batch stride xbs), stats [B][2][P] = (mean, rstd) of x over C or NULL (no
+ *   LayerNorm; then pack without gamma / beta), dw_w [4E][9], fft_w [E][8][5]
+ *   -> out [B][4E][H][W] = (out1|out2|out3|v_value_dw), exactly fdn_fdsa_core's output.
+ * C in {24, 32, 48, 64} (the two upper levels of FDN and FDN_lolv1), else FDN_ERR_UNSUPPORTED. */
+int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, float* bpk, int C, int E,
+                  fdn_stream_t stream);
+int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* bpk, const float* dw_w,
+                   const float* fft_w, float* out, int B, int C, int E, int H, int W, fdn_stream_t stream);
+
 /* FDSA tail in one launch (FDN_arch.py:633-639 and the residual add of :671): norm1/2/3 over the E channels
  * of out1|out2|out3, times v_value, project_out (3E -> N) + res, and (optionally) the channel LayerNorm
  * statistics of the result.  o [B][4E][P] as written by fdn_fdsa_core; w [N][3E]; gamma3,beta3 [3E];

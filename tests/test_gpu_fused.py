@@ -1,0 +1,98 @@
+"""GPU parity tests of the round-2 fused kernels: each fused launch against the unfused launches it replaces
+(same C ABI, same inputs) and against the CPU oracle."""
+import os
+import sys
+
+import pytest
+import torch
+
+import fdn_oracle as O
+from common import fdn_weights, fixture, fixture_weights, lpnet_weights, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import fdn_hip
+    fdn_hip.lib()   # fail loudly if the HIP extension is not built
+    from basicsr.models.archs import FDN_arch
+    return FDN_arch
+
+
+def dev(t):
+    return t.to("cuda:0").contiguous()
+
+
+def _rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("C,H,W,B,ln", [(32, 32, 64, 2, True), (32, 40, 48, 1, True), (64, 16, 40, 2, True), (24, 24, 72, 2, True),
+                                        (48, 8, 8, 3, True), (32, 16, 32, 1, False), (64, 368, 640, 1, True)])
+def test_fdsa_fused_equals_unfused(A, C, H, W, B, ln):
+    """fdn_fdsa_fused (LayerNorm + to_hidden on the matrix cores + core, one launch) against fdn_conv1x1 ->
+    fdn_fdsa_core on the same inputs: same MFMA chain order and the same spectral code, so equal to rounding."""
+    from fdn_hip import ops
+    E = int(C * 1.2)
+    x = dev(_rnd(B, C, H, W, seed=1) * 1.5 + 0.3)
+    w = dev(_rnd(4 * E, C, seed=2) / C ** 0.5)
+    g, b_ = dev(_rnd(C, seed=3) * 0.2 + 1.0), dev(_rnd(C, seed=4) * 0.1)
+    dw, fw = dev(_rnd(4 * E, 1, 3, 3, seed=5) / 3), dev(_rnd(E, 1, 1, 8, 5, seed=6) * 0.2 + 1.0)
+    if ln:
+        st = ops.chan_stats(x)
+        hidden = ops.conv1x1(x, w, ln=(st, g, b_))
+        wpk, bpk = ops.fdsa_pack(w, g, b_)
+    else:
+        st = None
+        hidden = ops.conv1x1(x, w)
+        wpk, bpk = ops.fdsa_pack(w, None, None)
+    ref = ops.fdsa_core(hidden, dw, fw)
+    got = ops.fdsa_fused(x, st, wpk, bpk, dw, fw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    assert rel_rms(got.cpu(), ref.cpu()) < 1e-7
+
+
+def test_fdsa_fused_batch_slices_and_edges(A):
+    """x handed over as a batch slice of a larger tensor; partial 32-wide tiles (W = 40); zero padding at every border."""
+    from fdn_hip import ops
+    C, E, H, W = 32, 38, 16, 40
+    big = dev(_rnd(5, C, H, W, seed=11))
+    x = big[1:4]
+    w = dev(_rnd(4 * E, C, seed=12) / C ** 0.5)
+    g, b_ = dev(torch.ones(C)), dev(_rnd(C, seed=13))          # a bias: the out-of-image halo must still read as 0
+    dw, fw = dev(_rnd(4 * E, 1, 3, 3, seed=14) / 3), dev(torch.ones(E, 1, 1, 8, 5))
+    st = ops.chan_stats(x.contiguous())
+    wpk, bpk = ops.fdsa_pack(w, g, b_)
+    got = ops.fdsa_fused(x, st, wpk, bpk, dw, fw)
+    ref = ops.fdsa_core(ops.conv1x1(x.contiguous(), w, ln=(st, g, b_)), dw, fw)
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+
+
+def test_forward_streams_cold_start(A):
+    """A freshly constructed model driven from three HIP streams at once: the derived weights (LayerNorm folds, packed
+    MFMA operands, BN folds) are built on whichever stream gets there first and every other stream must wait for them
+    (the first multi-stream call used to race)."""
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from fdn_hip.pipeline import forward_streams
+
+    def fresh():
+        net = A.FDN()
+        net.load_state_dict(fdn_weights(tame=0.03), strict=True)
+        lp = I_predict_net()
+        lp.load_state_dict(lpnet_weights(), strict=True)
+        return net.to("cuda:0").eval(), lp.to("cuda:0").eval()
+
+    x = dev(torch.rand(8, 3, 64, 96, generator=torch.Generator().manual_seed(21)))
+    net, lp = fresh()
+    cold = forward_streams(net, lp, x, 3)           # first call on a cold model, 3 streams (3, 2, 3 images)
+    torch.cuda.synchronize()
+    net2, lp2 = fresh()
+    ref = forward_streams(net2, lp2, x, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(cold, ref)

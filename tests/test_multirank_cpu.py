@@ -1,9 +1,12 @@
-"""CPU, gloo, world_size=2: the batch-sharding logic used on N GPUs.
+"""CPU, gloo, world_size=2: the batch-sharding code that runs over RCCL on N GPUs (fdn_hip/sharding.py
+is the module bench.py drives), and bench.py's own launcher (`--gpus 2` without torchrun) in its CPU rehearsal mode.
 
-The sharded run (scatter -> per-rank forward -> gather) must equal the single-process run bit for
-bit because no op mixes samples.  The per-rank forward here is the CPU oracle (checker only): the
-property under test is the sharding/collective plumbing, which is what runs over RCCL on GPUs."""
+The sharded run (scatter -> per-rank forward -> gather) must equal the single-process run bit for bit because no op
+mixes samples.  The per-rank forward here is the CPU oracle (checker only): the property under test is the
+sharding / collective plumbing."""
+import json
 import os
+import subprocess
 import sys
 
 import torch
@@ -11,13 +14,16 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, HERE)
-    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
     import fdn_oracle as O
     from common import fixture, fixture_weights
+    from fdn_hip import sharding                                   # host-side module: importable without a GPU
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -26,19 +32,20 @@ def _worker(rank, world, port, q):
     full_x = torch.cat([fx["x"], fx["x"].flip(0)])            # global batch 4 -> 2 per rank
     full_r = torch.cat([fx["ratio"], fx["ratio"].flip(0)])
     per = full_x.shape[0] // world
-    x, r = torch.empty(per, *full_x.shape[1:]), torch.empty(per, 1)
-    dist.scatter(x, list(full_x.chunk(world)) if rank == 0 else None, src=0)
-    dist.scatter(r, list(full_r.chunk(world)) if rank == 0 else None, src=0)
-    with torch.no_grad():
-        y = O.mar(x, r.view(-1, 1, 1, 1), P, "net_a")[2].contiguous()
-    outs = [torch.empty_like(y) for _ in range(world)] if rank == 0 else None
-    dist.gather(y, outs, dst=0)
-    t = torch.tensor([float(rank + 1)])
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)                   # the bench's max-over-ranks timing reduction
+    r = sharding.scatter_batch(dist, torch.empty(per, 1), sharding.split_batch(full_r, world) if rank == 0 else None)
+
+    def forward(x):
+        with torch.no_grad():
+            return O.mar(x, r.view(-1, 1, 1, 1), P, "net_a")[2].contiguous()
+
+    outs = [torch.empty(per, *fx["x"].shape[1:]) for _ in range(world)] if rank == 0 else None
+    sharding.sharded_step(dist, forward, torch.empty(per, *full_x.shape[1:]),
+                          sharding.split_batch(full_x, world) if rank == 0 else None, outs)
+    tmax = sharding.max_over_ranks(dist, float(rank + 1), torch.device("cpu"))   # the bench's max-over-ranks reduction
     if rank == 0:
         with torch.no_grad():
             ref = O.mar(full_x, full_r.view(-1, 1, 1, 1), P, "net_a")[2]
-        q.put((torch.equal(torch.cat(outs), ref), float(t.item())))
+        q.put((torch.equal(torch.cat(outs), ref), tmax))
     dist.destroy_process_group()
 
 
@@ -53,3 +60,31 @@ def test_sharded_equals_single_process():
     for p in procs:
         p.join(timeout=60)
     assert same and tmax == 2.0
+
+
+def test_shard_bounds():
+    sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+    from fdn_hip import sharding
+    assert sharding.shard_bounds(64, 8) == list(range(0, 65, 8))
+    assert sharding.shard_bounds(10, 4) == [0, 3, 6, 8, 10]
+    x = torch.arange(12).view(6, 2)
+    assert torch.equal(torch.cat(sharding.split_batch(x, 4)), x)
+
+
+def test_bench_launcher_spawns_gpus_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (it used to run one rank
+    and print n_gpus 1), push the scatter / gather through the timed loop and report the collective world size."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run",
+                        "--batch", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["global_batch"] == 6
+    assert line["config"]["scatter_gather_timed"] is True and "without_collectives" in line and line["dry_run"] is True
+
+
+def test_bench_rejects_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)

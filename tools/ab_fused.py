@@ -1,0 +1,39 @@
+"""A/B timing of the fused patch kernels at the bench shapes: tools/ab_fused.py [lib.so ...] (default: the in-tree library).
+Each library is timed in its own child process (the binding loads one library per process)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] != "--child":
+    for lib in sys.argv[1:]:
+        print("==", lib, flush=True)
+        subprocess.run([sys.executable, __file__, "--child", lib])
+    sys.exit(0)
+sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+import fdn_hip
+if len(sys.argv) > 2 and sys.argv[2] != "default":
+    fdn_hip._LIB_PATH = os.path.abspath(sys.argv[2])
+import torch
+from fdn_hip import ops
+dev = torch.device("cuda:0")
+B, H0, W0 = 8, 736, 1280
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+for lvl in (1, 2):
+    C = 32 * 2 ** (lvl - 1); H, W = H0 >> (lvl - 1), W0 >> (lvl - 1)
+    E, Hd = int(C * 1.2), int(C * 2.7)
+    r = lambda *s: torch.randn(*s, device=dev)
+    x = r(B, C, H, W); st = ops.chan_stats(x); g, b_ = r(C), r(C)
+    wh = r(4 * E, C) / C ** .5; dw, fw = r(4 * E, 1, 3, 3), r(E, 1, 1, 8, 5)
+    wpk, bpk = ops.fdsa_pack(wh, g, b_)
+    print(f"L{lvl} fdsa_fused {timeit(lambda: ops.fdsa_fused(x, st, wpk, bpk, dw, fw)):.3f} ms", flush=True)
+    if hasattr(ops, "fdffn_fused"):
+        wi = r(Hd, C) / C ** .5
+        w0, w2, fa, fp = r(Hd, 1, 3, 3), r(Hd, 1, 3, 3), r(Hd, 1, 1, 8, 5), r(Hd, 1, 1, 8, 5)
+        pk = ops.fdffn_pack(wi, g, b_)
+        print(f"L{lvl} fdffn_fused {timeit(lambda: ops.fdffn_fused(x, st, pk[0], pk[1], w0, w2, fa, fp)):.3f} ms", flush=True)
