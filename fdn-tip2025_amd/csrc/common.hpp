@@ -71,3 +71,69 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
 __device__ __forceinline__ float cabs2(float2 a) { return sqrtf(a.x * a.x + a.y * a.y); }
+
+// ------------------------------------------------------------------------------------------------
+// bf16 STORAGE of block-internal activations (BASELINE.json configs[2]).  bf16 is only a
+// memory format here: a value is widened to fp32 when loaded (exact) and rounded to nearest-even when stored
+// (v_cvt_pk_bf16_f32, NaN stays NaN); every product, sum, FFT and LayerNorm statistic is fp32.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned fdn_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned fdn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+// element loads / stores through a raw buffer resource; `voff` / `soff` are BYTE offsets of the storage type
+template <bool BF>
+__device__ __forceinline__ float st_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (BF) return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0) << 16);
+    else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+template <bool BF>
+__device__ __forceinline__ void st_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (BF) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack_bf16(v, 0.f) & 0xFFFFu), r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+template <bool BF>
+__device__ __forceinline__ void st_load2(float (&v)[2], __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (BF) {
+        const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+        v[0] = bf16_lo(u);
+        v[1] = bf16_hi(u);
+    } else {
+        const fdn_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        v[0] = __uint_as_float(u.x);
+        v[1] = __uint_as_float(u.y);
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void st_store2(const float (&v)[2], __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (BF) __builtin_amdgcn_raw_buffer_store_b32(pack_bf16(v[0], v[1]), r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}, r, voff, soff, 0);
+}
+template <bool BF>
+__device__ __forceinline__ void st_load4(float (&v)[4], __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (BF) {
+        const fdn_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        v[0] = bf16_lo(u.x); v[1] = bf16_hi(u.x); v[2] = bf16_lo(u.y); v[3] = bf16_hi(u.y);
+    } else {
+        const fdn_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void st_store8(const float (&v)[8], __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (BF) {
+        __builtin_amdgcn_raw_buffer_store_b128(fdn_u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])},
+                                               r, voff, soff, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b128(fdn_u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                               r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(fdn_u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])},
+                                               r, voff + 16u, soff, 0);
+    }
+}
+template <bool BF> constexpr unsigned st_bytes() { return BF ? 2u : 4u; }

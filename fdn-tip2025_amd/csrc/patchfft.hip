@@ -352,7 +352,7 @@ constexpr int CPB = 4;                                  // channels per workgrou
 constexpr int HALO2 = (TH + 4) * (TW + 4);
 constexpr int HPT2 = (HALO2 + 255) / 256;               // 10 elements per thread
 
-template <bool V4>
+template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as bf16 (fp32 math either way; V4 needs fp32 input)
 __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                            const float* __restrict__ w2, const float* __restrict__ ffta,
                                                            const float* __restrict__ fftp, float* __restrict__ out, int Hd,
@@ -365,13 +365,15 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
     const int tid = threadIdx.x;
     const int cbase = blockIdx.y * CPB, b = blockIdx.z;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    const unsigned hw4 = (unsigned)H * W * 4u;                  // bytes per plane; Hd planes per image < 4 GB (checked by the host)
-    const rsrc_t rin = mk_rsrc(x + (long)b * Hd * H * W, (unsigned)Hd * hw4);
-    const rsrc_t rout = mk_rsrc(out + (long)b * Hd * H * W, (unsigned)Hd * hw4);
+    constexpr unsigned IES = st_bytes<IBF>(), OES = st_bytes<OBF>();
+    const unsigned hw4 = (unsigned)H * W * IES;                 // bytes per input plane; Hd planes per image < 4 GB (checked by the host)
+    const unsigned hwo = (unsigned)H * W * OES;
+    const rsrc_t rin = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (long)b * Hd * H * W * IES), (unsigned)Hd * hw4);
+    const rsrc_t rout = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(out) + (long)b * Hd * H * W * OES), (unsigned)Hd * hwo);
     const int patch = tid >> 3, rr = tid & 7;
     const int py = patch >> 3, px = patch & 7;
     const int gy = ty0 + py * 8 + rr, gx = tx0 + px * 8;
-    const unsigned ooff = (gy < H && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOB;
+    const unsigned ooff = (gy < H && gx < W) ? (unsigned)(gy * W + gx) * OES : OOB;
 
     unsigned goff[HPT2];
     int slot[HPT2];
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
         const int r = idx / (TW + 4), cc = idx - r * (TW + 4);
         const int y = ty0 - 2 + r, xx = tx0 - 2 + cc;
         const bool ok = idx < HALO2 && y >= 0 && y < H && xx >= 0 && xx < W;
-        goff[i] = ok ? (unsigned)(y * W + xx) * 4u : OOB;
+        goff[i] = ok ? (unsigned)(y * W + xx) * IES : OOB;
         slot[i] = idx < HALO2 ? r * LS2 + cc : (TH + 4) * LS2;
     }
     float pre[HPT2];
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
     auto fetch = [&](int c) {
         if (V4) { halo_v4_fetch(rin, (unsigned)c * hw4, hv, hd); return; }
 #pragma unroll
-        for (int i = 0; i < HPT2; ++i) pre[i] = bload(rin, goff[i], (unsigned)c * hw4);
+        for (int i = 0; i < HPT2; ++i) pre[i] = st_load1<IBF>(rin, goff[i], (unsigned)c * hw4);
     };
     auto stash = [&]() {
         if (V4) { halo_v4_stash(tin, hv, hd); return; }
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
             irfft8_row(xk, r);
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] += sp[j];                                                              // :470
-            bstore8(r, rout, ooff, (unsigned)c * hw4);
+            st_store8<OBF>(r, rout, ooff, (unsigned)c * hwo);
         }
         __syncthreads();                                          // S, mid, filt are rewritten by the next channel
     }
@@ -565,7 +567,7 @@ struct FusedArgs {
     int E, H, W, tiles_x, tiles_per_img, nchunks;
 };
 
-template <int C, bool LN>
+template <int C, bool LN, bool OBF>          // OBF: the (out1|out2|out3|v_value) planes are stored as bf16
 __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     __shared__ float hid[32 * FPL + 4];
     __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
@@ -582,7 +584,9 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     const unsigned P = (unsigned)H * W, hw4 = P * 4u;
     const rsrc_t rx = mk_rsrc(a.x + (long)b * a.xbs, (unsigned)C * hw4);
     const rsrc_t rst = mk_rsrc(LN ? a.stats + (long)b * 2 * P : a.x, LN ? 2u * hw4 : 0u);
-    const rsrc_t rout = mk_rsrc(a.out + (long)b * 4 * E * P, 4u * E * hw4);
+    constexpr unsigned OES = st_bytes<OBF>();
+    const unsigned hwo = P * OES;
+    const rsrc_t rout = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.out) + (long)b * 4 * E * P * OES), 4u * E * hwo);
 
     // ---- the wave's strips of the normalised halo tile: B operands, resident for the whole workgroup ----------
     float xs[3][C / 2];
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     const int row = lane & 7, px = (lane >> 3) & 3;
     const int slot = el * 4 + px;
     const int gx0 = tx0 + px * 8;
-    const unsigned opix = gx0 < W ? (unsigned)((ty0 + row) * W + gx0) * 4u : OOB;
+    const unsigned opix = gx0 < W ? (unsigned)((ty0 + row) * W + gx0) * OES : OOB;
     const float* hb = hid + el * FPL + row * FRS + px * 8;
 
     for (int ch = 0; ch < a.nchunks; ++ch) {
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
 #pragma unroll
                 for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * 8 + row] = sp[kx];
             } else {
-                bstore8(o8, rout, e < E ? opix + (unsigned)(3 * E + e) * hw4 : OOB, 0);
+                st_store8<OBF>(o8, rout, e < E ? opix + (unsigned)(3 * E + e) * hwo : OOB, 0);
             }
         }
         __syncthreads();
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
             for (int kx = 0; kx < 5; ++kx) xk[kx] = S[(t * NP + slot) * PS + kx * 8 + row];
             float r8[8];
             irfft8_row(xk, r8);
-            bstore8(r8, rout, e < E ? opix + (unsigned)(t * E + e) * hw4 : OOB, 0);
+            st_store8<OBF>(r8, rout, e < E ? opix + (unsigned)(t * E + e) * hwo : OOB, 0);
         }
         // (the next chunk's MFMA phase writes `hid`, free since the second barrier; its row phase rewrites S behind
         //  the barrier that follows the MFMA phase, i.e. after every thread has finished these reads)
@@ -799,8 +803,10 @@ extern "C" int fdn_fdsa_core(const float* hidden, const float* dw_w, const float
     return fdn_launch_status();
 }
 
-extern "C" int fdn_fdffn_mid(const float* x, const float* w0, const float* w2, const float* ffta, const float* fftp,
-                             float* out, int B, int Hd, int H, int W, fdn_stream_t stream) {
+extern "C" int fdn_fdffn_mid(const void* x_, const float* w0, const float* w2, const float* ffta, const float* fftp,
+                             void* out_, int B, int Hd, int H, int W, int x_bf16, int out_bf16, fdn_stream_t stream) {
+    const float* x = static_cast<const float*>(x_);
+    float* out = static_cast<float*>(out_);
     FDN_CHECK_ARG(x && w0 && w2 && ffta && fftp && out && B > 0 && Hd > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0 && Hd < 65536 && B < 65536);
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -808,8 +814,12 @@ extern "C" int fdn_fdffn_mid(const float* x, const float* w0, const float* w2, c
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     // (the 16-byte-lane halo fetch, V4 = true, measured slower here - 1.95 vs 1.80 ms at level 1: this kernel is bound by
     // VALU issue, and the float4 stash costs four LDS writes per load)
-    hipLaunchKernelGGL(fdffn_mid_kernel<false>, dim3(tx * ty, (Hd + CPB - 1) / CPB, B), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                       w0, w2, ffta, fftp, out, Hd, H, W, tx);
+    const dim3 grid(tx * ty, (Hd + CPB - 1) / CPB, B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (x_bf16 && out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx);
+    else if (x_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx);
+    else if (out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, false, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx);
+    else hipLaunchKernelGGL((fdffn_mid_kernel<false, false, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx);
     return fdn_launch_status();
 }
 
@@ -824,7 +834,8 @@ extern "C" int fdn_fdsa_pack(const float* w, const float* gamma, const float* be
 }
 
 extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* bpk, const float* dw_w,
-                              const float* fft_w, float* out, int B, int C, int E, int H, int W, fdn_stream_t stream) {
+                              const float* fft_w, void* out_, int B, int C, int E, int H, int W, int out_bf16, fdn_stream_t stream) {
+    float* out = static_cast<float*>(out_);
     FDN_CHECK_ARG(x && wpk && bpk && dw_w && fft_w && out && B > 0 && E > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0);
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
@@ -839,10 +850,12 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
     FDN_CHECK_ARG(total < 0x7fffffffL);
     const dim3 grid((unsigned)total), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define FDN_FUSED_CASE(CC)                                                                       \
-    case CC:                                                                                     \
-        if (stats) hipLaunchKernelGGL((fdsa_fused_kernel<CC, true>), grid, block, 0, s, a);      \
-        else hipLaunchKernelGGL((fdsa_fused_kernel<CC, false>), grid, block, 0, s, a);           \
+#define FDN_FUSED_CASE(CC)                                                                                        \
+    case CC:                                                                                                      \
+        if (stats && out_bf16) hipLaunchKernelGGL((fdsa_fused_kernel<CC, true, true>), grid, block, 0, s, a);     \
+        else if (stats) hipLaunchKernelGGL((fdsa_fused_kernel<CC, true, false>), grid, block, 0, s, a);           \
+        else if (out_bf16) hipLaunchKernelGGL((fdsa_fused_kernel<CC, false, true>), grid, block, 0, s, a);        \
+        else hipLaunchKernelGGL((fdsa_fused_kernel<CC, false, false>), grid, block, 0, s, a);                     \
         break;
     switch (C) {
         FDN_FUSED_CASE(24)

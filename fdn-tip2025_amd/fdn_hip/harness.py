@@ -75,8 +75,10 @@ def enhance_u8(net, lpnet, img_u8, bgr=True, ratio_mode="lolblur"):
     if ratio_mode not in ("lolblur", "lolv1"):
         raise ValueError(f"ratio_mode {ratio_mode!r}")
     x, h, w = preprocess(img_u8, bgr=bgr)
-    ratio = lpnet(x)
-    if ratio_mode == "lolv1":
-        ratio = lolv1_ratio(x, ratio)
-    result = net(x, ratio_i=ratio, device=x.device)[0]
+    if ratio_mode == "lolblur":
+        from .pipeline import run
+        result = run(net, lpnet, x)                # hipGraph replay for small frames, HIP streams for large batches
+    else:
+        ratio = lolv1_ratio(x, lpnet(x))
+        result = net(x, ratio_i=ratio, device=x.device)[0]
     return postprocess(result.contiguous(), h, w, bgr=bgr)

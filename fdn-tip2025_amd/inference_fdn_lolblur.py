@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--lpnet", required=True, help="LPNet checkpoint (292 keys)")
     ap.add_argument("--input", required=True, help="glob of input frames")
     ap.add_argument("--output", required=True, help="output directory")
+    ap.add_argument("--input-root", default=None,
+                    help="directory the output tree mirrors: a frame <input-root>/0256/0089.png is written to <output>/0256/0089.png "
+                         "(the reference keeps the LOL-Blur sequence folders the same way, inference_fdn_lolblur.py:44-45,73); "
+                         "default: the common parent directory of all input frames")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--device", default="cuda:0")
     a = ap.parse_args()
@@ -62,6 +66,12 @@ def main():
     paths = sorted(glob.glob(a.input))
     if not paths:
         raise SystemExit(f"no input frames match {a.input}")
+    root = a.input_root or os.path.commonpath([os.path.dirname(os.path.abspath(p)) for p in paths])
+    dest = {p: os.path.join(a.output, os.path.relpath(os.path.abspath(p), root)) for p in paths}
+    if any(d.startswith("..") for d in (os.path.relpath(v, a.output) for v in dest.values())):
+        raise SystemExit(f"--input-root {root} does not contain every input frame")
+    if len(set(dest.values())) != len(paths):                              # never let two frames race for one output file
+        raise SystemExit("two input frames map to the same output path; pass an --input-root above both")
     with ThreadPoolExecutor(max_workers=4) as pool:
         decoded = pool.map(read_rgb, paths)                               # decode runs ahead of the GPU
         pending, writers = [], []
@@ -72,7 +82,7 @@ def main():
             batch = torch.from_numpy(np.stack([im for _, im in pending])).to(dev, non_blocking=True)
             out = enhance_u8(net, lp, batch, bgr=False).cpu().numpy()
             for (p, _), o in zip(pending, out):
-                writers.append(pool.submit(write_rgb, os.path.join(a.output, os.path.basename(p)), o))
+                writers.append(pool.submit(write_rgb, dest[p], o))
             pending.clear()
 
         for p, im in zip(paths, decoded):

@@ -79,8 +79,9 @@ def bilinear_x2(x):
 # --------------------------------------------------------------------------------------
 # FDformer blocks
 # --------------------------------------------------------------------------------------
-def fdsa(x, P, pfx):
-    """Frequency-domain self attention, FDN_arch.py:575-641."""
+def fdsa(x, P, pfx, taps=None):
+    """Frequency-domain self attention, FDN_arch.py:575-641.  taps: optional dict that receives the inputs of
+    norm1/2/3 (:633-635) as 'o1','o2','o3' and v_value as 'vv' (what a forward hook on the reference sees)."""
     w_h = P[pfx + ".to_hidden.weight"]
     hidden = F.conv2d(x, w_h)                                                    # :576
     hidden = F.conv2d(hidden, P[pfx + ".to_hidden_dw.weight"], padding=1,
@@ -98,14 +99,17 @@ def fdsa(x, P, pfx):
     o1 = from_patches(torch.fft.irfft2(polar(v_a, qkp), s=s))                    # :609-614
     o2 = from_patches(torch.fft.irfft2(polar(qka, v_p), s=s))                    # :617-620
     o3 = from_patches(torch.fft.irfft2(polar(qka, qkp), s=s))                    # :627-630
+    if taps is not None:
+        taps.update(o1=o1, o2=o2, o3=o3, vv=vv)
     o1 = _ln(o1, P, pfx + ".norm1") * vv                                         # :633,636
     o2 = _ln(o2, P, pfx + ".norm2") * vv
     o3 = _ln(o3, P, pfx + ".norm3") * vv
     return F.conv2d(torch.cat([o1, o2, o3], dim=1), P[pfx + ".project_out.weight"])  # :639
 
 
-def fdffn(x, P, pfx):
-    """Frequency-domain feed-forward, FDN_arch.py:453-475 (x_high/xp2/x_img are ignored there)."""
+def fdffn(x, P, pfx, taps=None):
+    """Frequency-domain feed-forward, FDN_arch.py:453-475 (x_high/xp2/x_img are ignored there).
+    taps: optional dict that receives the input of `dwconv` (:472) as 'mid'."""
     x = F.conv2d(x, P[pfx + ".project_in.weight"])                               # :456
     hd = x.shape[1]
     s = F.conv2d(x, P[pfx + ".space.0.weight"], padding=1, groups=hd)
@@ -113,18 +117,23 @@ def fdffn(x, P, pfx):
     z = replace_denormals(torch.fft.rfft2(to_patches(x)))                        # :458-461
     z = polar(z.abs() * P[pfx + ".ffta"], z.angle() - P[pfx + ".fftp"])          # :462-468
     x = from_patches(torch.fft.irfft2(z, s=(PATCH, PATCH))) + s                  # :469-470
+    if taps is not None:
+        taps.update(mid=x)
     x1, x2 = F.conv2d(x, P[pfx + ".dwconv.weight"], padding=1, groups=hd).chunk(2, dim=1)  # :472
     return F.conv2d(F.gelu(x1) * x2, P[pfx + ".project_out.weight"])             # :473-474
 
 
-def fcaffn(x, amp, pha, img, P, pfx):
-    """Fourier cross-attention FFN (encoder blocks only), FDN_arch.py:405-429."""
+def fcaffn(x, amp, pha, img, P, pfx, taps=None):
+    """Fourier cross-attention FFN (encoder blocks only), FDN_arch.py:405-429.
+    taps: optional dict that receives the input of `norm` (:420), i.e. the irfft2 result, as 'xi'."""
     h, w = x.shape[-2:]
     x1 = x
     z = replace_denormals(torch.fft.rfft2(x))                                    # :411-412
     z_p = z.angle() - F.conv2d(pha, P[pfx + ".conv1_xp.weight"])                 # :413
     z_a = F.conv2d(amp, P[pfx + ".conv1_xa.weight"]) * z.abs()                   # :414-415
     x = torch.fft.irfft2(polar(z_a, z_p), s=(h, w))                              # :417-418
+    if taps is not None:
+        taps.update(xi=x)
     x = _ln(x, P, pfx + ".norm") * x1 + x1                                       # :420
     x = F.conv2d(x, P[pfx + ".project_in.weight"])                               # :421
     c = x.shape[1]

@@ -216,3 +216,55 @@ def test_metrics_against_reference_functions():
     for name, x, y, ref in _metric_cases():
         assert abs(O.calculate_psnr(x, y, ref["crop_border"]) - ref["psnr"]) < 1e-9, name
         assert abs(O.ssim_3d(x, y, ref["crop_border"]) - ref["ssim"]) < 1e-6, name
+
+
+# --------------------------------------------------------------------------------------------------------------
+# replace_denormals edge cases and dark inputs (fixtures of tests/golden/make_golden_edge.py: module outputs AND the
+# reference's own intermediate tensors captured by forward hooks)
+# --------------------------------------------------------------------------------------------------------------
+def test_edge_fdsa_regions_and_wholesale_replaced_spectra():
+    import edge_cases as EC
+    fx, sd = EC.fdsa_edge()
+    taps = {}
+    with torch.no_grad():
+        y = O.fdsa(fx["x"], {"." + k: v for k, v in sd.items()}, "", taps)
+    for k in ("o1", "o2", "o3"):
+        EC.assert_regions_close(taps[k], fx[k], "fdsa_edge." + k, 1e-6)
+        EC.assert_channels_close(taps[k], fx[k], "fdsa_edge." + k, 1e-5)
+    assert rel_rms(y, fx["y"]) < 1e-6
+    # the zero / -0 patches really are the all-replaced case: every bin (1e-10, 1e-10) -> an impulse of sqrt(2) * 1e-10
+    r0, r1, c0, c1 = EC.REGIONS["zero"]
+    assert abs(fx["o1"][0, 0, r0, c0].item() - 2 ** 0.5 * 1e-10) < 1e-15 and fx["o1"][0, 0, r0 + 1:r1, c0:c1].abs().max() < 1e-16
+
+
+def test_edge_fdsa_threshold_impulses():
+    import edge_cases as EC
+    fx, sd = EC.fdsa_kat()
+    taps = {}
+    with torch.no_grad():
+        y = O.fdsa(fx["x"], {"." + k: v for k, v in sd.items()}, "", taps)
+    for k in ("o1", "o2", "o3"):
+        EC.assert_channels_close(taps[k], fx[k], "fdsa_kat." + k, 1e-6)
+    assert rel_rms(y, fx["y"]) < 1e-6
+
+
+def test_edge_fdffn_fcaffn_and_dark_e2e():
+    import edge_cases as EC
+    fx, sd = EC.fdffn_edge()
+    taps = {}
+    with torch.no_grad():
+        y = O.fdffn(fx["x"], {"." + k: v for k, v in sd.items()}, "", taps)
+    EC.assert_regions_close(taps["mid"], fx["mid"], "fdffn_edge.mid", 1e-6)
+    EC.assert_channels_close(taps["mid"], fx["mid"], "fdffn_edge.mid", 1e-5)
+    assert rel_rms(y, fx["y"]) < 1e-6
+    fx, sd = EC.fcaffn_edge()
+    taps = {}
+    with torch.no_grad():
+        y = O.fcaffn(fx["x"], fx["amp"], fx["pha"], fx["img"], {"." + k: v for k, v in sd.items()}, "", taps)
+    EC.assert_channels_close(taps["xi"], fx["xi"], "fcaffn_edge.xi", 1e-5)
+    assert rel_rms(y, fx["y"]) < 1e-5
+    fx = fixture("fdn_tamed_64_dark")
+    with torch.no_grad():
+        outs = O.fdn_forward(fdn_weights(tame=float(fx["tame"])), fx["x"], fx["ratio"])
+    for got, key in zip(outs, ("y", "q1", "q2", "q3")):
+        assert O.psnr(got, fx[key]) > 110.0, key
