@@ -80,13 +80,15 @@ def describe_call(name, a):
     if name == "fdn_conv1x1":
         d = a[0]._obj
         f = 2.0 * d.B * d.K * d.N * d.P
-        b = 4.0 * d.B * d.P * (d.K + d.N + (d.N if d.epi == 1 else 0) + (2 * d.N if d.epi == 2 else 0)
-                               + (d.K // 3 if d.pro == 2 else 0) + (d.K if d.pro == 3 else 0))
-        key = f"fdn_conv1x1[{d.K}->{d.N},pro{d.pro},epi{d.epi},P={d.P}]"
+        b = d.B * d.P * ((2.0 if d.x_bf16 else 4.0) * d.K + (2.0 if d.out_bf16 else 4.0) * d.N
+                         + 4.0 * ((d.N if d.epi == 1 else 0) + (2 * d.N if d.epi == 2 else 0)
+                                  + (d.K // 3 if d.pro == 2 else 0) + (d.K if d.pro == 3 else 0)))
+        key = f"fdn_conv1x1[{d.K}->{d.N},pro{d.pro},epi{d.epi},P={d.P}{',xbf16' if d.x_bf16 else ''}{',obf16' if d.out_bf16 else ''}]"
     elif name == "fdn_fdsa_fused":
-        B, C, E, H, W = (_iv(v) for v in a[8:13])
-        f, b = 2.0 * B * H * W * C * 4 * E, 4.0 * B * H * W * (C + 4 * E)
-        key = f"fdn_fdsa_fused[C={C},E={E},{H}x{W}]"
+        B, C, E, H, W = (_iv(v) for v in a[7:12])
+        ob = 2.0 if _iv(a[12]) else 4.0
+        f, b = 2.0 * B * H * W * C * 4 * E, B * H * W * (4.0 * C + ob * 4 * E)
+        key = f"fdn_fdsa_fused[C={C},E={E},{H}x{W}{',obf16' if ob == 2.0 else ''}]"
     elif name == "fdn_fdffn_fused":
         B, C, Hd, H, W = (_iv(v) for v in a[10:15])
         f, b = 2.0 * B * H * W * C * Hd, 4.0 * B * H * W * (C + Hd)
@@ -97,16 +99,19 @@ def describe_call(name, a):
         key = f"fdn_fdsa_core[E={E},{H}x{W}]"
     elif name == "fdn_fdsa_out":
         B, E, N, P = (_iv(v) for v in a[7:11])
-        f, b = 2.0 * B * P * 3 * E * N, 4.0 * B * P * (4 * E + 2 * N)
-        key = f"fdn_fdsa_out[E={E},N={N},P={P}]"
+        ib = 2.0 if _iv(a[11]) else 4.0
+        f, b = 2.0 * B * P * 3 * E * N, B * P * (ib * 4 * E + 4.0 * 2 * N)
+        key = f"fdn_fdsa_out[E={E},N={N},P={P}{',ibf16' if ib == 2.0 else ''}]"
     elif name == "fdn_fdffn_mid":
         B, Hd, H, W = (_iv(v) for v in a[6:10])
-        b = 4.0 * B * H * W * 2 * Hd
-        key = f"fdn_fdffn_mid[Hd={Hd},{H}x{W}]"
+        ib, ob = (2.0 if _iv(a[10]) else 4.0), (2.0 if _iv(a[11]) else 4.0)
+        b = B * H * W * Hd * (ib + ob)
+        key = f"fdn_fdffn_mid[Hd={Hd},{H}x{W}{',bf16' if ib + ob < 8 else ''}]"
     elif name == "fdn_dwconv_gate":
         B, C, H, W = (_iv(v) for v in a[3:7])
-        b = 4.0 * B * H * W * 2 * C
-        key = f"fdn_dwconv_gate[C={C},{H}x{W}]"
+        ib, ob = (2.0 if _iv(a[7]) else 4.0), (2.0 if _iv(a[8]) else 4.0)
+        b = B * H * W * C * (ib + ob)
+        key = f"fdn_dwconv_gate[C={C},{H}x{W}{',bf16' if ib + ob < 8 else ''}]"
     elif name == "fdn_ffn_tail":
         B, C, N, H, W = (_iv(v) for v in a[6:11])
         f, b = 2.0 * B * H * W * C * N, 4.0 * B * H * W * (C + 2 * N)

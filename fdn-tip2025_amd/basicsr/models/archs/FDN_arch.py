@@ -82,9 +82,10 @@ class FDSA(nn.Module):
         e = self.expand_dim
         if x.shape[1] in ops.FDSA_FUSED_C:      # levels 1-2: LayerNorm + to_hidden + core in one launch, no hidden tensor in HBM
             srcs = [self.to_hidden.weight] + ([ln[1], ln[2]] if ln is not None else [])
-            wpk, bpk = self._c.get("pk" if ln is not None else "pk0", srcs, lambda: ops.fdsa_pack(
+            wpk = self._c.get("pk" if ln is not None else "pk0", srcs, lambda: ops.fdsa_pack(
                 _w(self.to_hidden.weight), *((ln[1], ln[2]) if ln is not None else (None, None))))
-            o = ops.fdsa_fused(x, ln[0] if ln is not None else None, wpk, bpk, _w(self.to_hidden_dw.weight), _w(self.fft))
+            o = ops.fdsa_fused(x, ln[0] if ln is not None else None, wpk, _w(self.to_hidden_dw.weight), _w(self.fft),
+                               out_dtype=ops.block_storage(x.shape[1], x.shape[2] * x.shape[3]))
         else:
             hidden = ops.conv1x1(x, _w(self.to_hidden.weight), ln=ln, cache=(self._c, "th"))
             o = ops.fdsa_core(hidden, _w(self.to_hidden_dw.weight), _w(self.fft))
@@ -122,7 +123,8 @@ class FDFFN(nn.Module):
         self._c = _Cache()
 
     def fused(self, x, ln=None, res=None):
-        h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln, cache=(self._c, "pi"))
+        st = ops.block_storage(x.shape[1], x.shape[2] * x.shape[3])      # hidden tensors: fp32, or bf16 storage (levels 1-2 in bf16 mode)
+        h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln, cache=(self._c, "pi"), out_dtype=st)
         y = ops.fdffn_mid(h, _w(self.space[0].weight), _w(self.space[2].weight), _w(self.ffta), _w(self.fftp))
         return ops.ffn_tail(y, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None)
 

@@ -1,7 +1,7 @@
 // ABI bookkeeping for libfdn_hip.so.
 #include "common.hpp"
 
-extern "C" int fdn_abi_version(void) { return 5; }
+extern "C" int fdn_abi_version(void) { return 6; }
 
 extern "C" const char* fdn_error_string(int code) {
     switch (code) {
@@ -12,4 +12,65 @@ extern "C" const char* fdn_error_string(int code) {
         case FDN_ERR_UNSUPPORTED: return "configuration not supported by this build";
         default: return "unknown error";
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-device launch state (declared in common.hpp)
+// ------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <map>
+#include <utility>
+
+namespace {
+std::mutex g_mu;
+int g_cus_by_dev[64];                                             // 0 = not queried yet
+std::map<std::pair<const void*, int>, size_t> g_lds_limit;         // (kernel, device) -> dynamic LDS bytes already allowed
+struct OccKey {
+    const void* k; int dev, threads; size_t lds;
+    bool operator<(const OccKey& o) const {
+        if (k != o.k) return k < o.k;
+        if (dev != o.dev) return dev < o.dev;
+        if (threads != o.threads) return threads < o.threads;
+        return lds < o.lds;
+    }
+};
+std::map<OccKey, int> g_occ;
+}  // namespace
+
+bool fdn_occupancy(int* blocks_per_cu, const void* kernel, int threads, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const OccKey key{kernel, dev, threads, lds};
+    auto it = g_occ.find(key);
+    if (it == g_occ.end()) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess) return false;
+        it = g_occ.emplace(key, n).first;
+    }
+    *blocks_per_cu = it->second;
+    return true;
+}
+
+int fdn_device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_cus_by_dev[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return -1;
+        g_cus_by_dev[dev] = n;
+    }
+    return g_cus_by_dev[dev];
+}
+
+bool fdn_allow_dynamic_lds(const void* kernel, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(g_mu);
+    size_t& have = g_lds_limit[std::make_pair(kernel, dev)];
+    if (have >= bytes) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    have = bytes;
+    return true;
 }

@@ -17,6 +17,13 @@ static inline int fdn_launch_status() {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Launch-time device facts, cached per device ordinal (a process may drive several GPUs from several threads; plain
+// function-local statics would freeze the first device's answer).  fdn_device_cus: compute units of the CURRENT device
+// (<= 0 on error).  fdn_allow_dynamic_lds: raise a kernel's dynamic-LDS limit once per (kernel, device).
+int fdn_device_cus();
+bool fdn_allow_dynamic_lds(const void* kernel, size_t bytes);
+bool fdn_occupancy(int* blocks_per_cu, const void* kernel, int threads, size_t lds);   // hipOccupancyMaxActiveBlocksPerMultiprocessor, cached
+
 __device__ __forceinline__ float gelu_erf(float x) {
     // F.gelu default (erf form), FDN_arch.py:427,438,473
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

@@ -163,22 +163,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_kernel(C3Arg
     }
 }
 
-int g_cus = 0;
-
 template <int MT, int NW>
 int launch(C3Args a, hipStream_t s) {
     const size_t lds = 2UL * KC * (MT * 32 + 1) * sizeof(float);
-    if (g_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int g_cus = fdn_device_cus();
+    if (g_cus <= 0) return FDN_ERR_LAUNCH;
     a.tiles_per_img = cdiv((long)a.H * a.W, NW * 32);
     a.total_tiles = a.B * a.tiles_per_img;
     // 4-wave workgroups, two (independent) per CU: their per-chunk barriers drift apart (as in gemm1x1.hip)
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(conv3x3_kernel<MT, NW>), NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (!fdn_occupancy(&per_cu, reinterpret_cast<const void*>(conv3x3_kernel<MT, NW>), NW * 64, lds) || per_cu < 1) per_cu = 1;
     if (per_cu * NW > 16) per_cu = 16 / NW;
     int grid = g_cus * per_cu;
     if (grid > a.total_tiles) grid = a.total_tiles;

@@ -78,7 +78,7 @@ constexpr int HPT = (HALO + 255) / 256;   // 9 halo elements per thread
 // branch, and (C+2m)/2, (C+2m+1)/2 for the gate branch (the same channel when C is even), so every
 // input plane is read once instead of twice.  A thread walks 8 rows of one column with a sliding 3x3
 // window per plane (3 LDS reads per row and plane instead of 9).
-template <bool SAME>
+template <bool SAME, bool OBF>
 __device__ __forceinline__ void dw_gate_rows(const float* ta, const float* tb0, const float* tb1, const float (&wa0)[9],
                                              const float (&wb0)[9], const float (&wa1)[9], const float (&wb1)[9], bool has1, int r0,
                                              int cx, rsrc_t rout, unsigned voff0, unsigned row4, int rows_ok, unsigned plane0,
@@ -109,15 +109,16 @@ __device__ __forceinline__ void dw_gate_rows(const float* ta, const float* tb0, 
                 g1 = fmaf(wb1[dy * 3 + dx], SAME ? p[k][dx] : q[k][dx], g1);
             }
         if (i < rows_ok) {                                                   // wave-uniform
-            bstore(gelu_fast(s0) * g0, rout, voff0, plane0 + (unsigned)i * row4);
-            if (has1) bstore(gelu_fast(s1) * g1, rout, voff0, plane1 + (unsigned)i * row4);
+            st_store1<OBF>(gelu_fast(s0) * g0, rout, voff0, plane0 + (unsigned)i * row4);
+            if (has1) st_store1<OBF>(gelu_fast(s1) * g1, rout, voff0, plane1 + (unsigned)i * row4);
         }
     }
 }
 
-template <bool V4>
+template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as bf16 (fp32 math either way)
 __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       float* __restrict__ out, int C, int H, int W, int tiles_x) {
+    constexpr unsigned IES = st_bytes<IBF>(), OES = st_bytes<OBF>();
     __shared__ float ta[(TH + 2) * LS + 4];
     __shared__ float tb[2][(TH + 2) * LS + 4];
     const int m = blockIdx.y, b = blockIdx.z;
@@ -126,9 +127,9 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
     const int cb0 = (C + j0) >> 1, cb1 = (C + j1) >> 1;     // grouped conv: output o reads input o/2
     const bool same = cb1 == cb0 || !has1;
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    const unsigned hw4 = (unsigned)H * W * 4u;
-    const rsrc_t rin = mk_rsrc(x + (long)b * C * H * W, (unsigned)C * hw4);
-    const rsrc_t rout = mk_rsrc(out + (long)b * C * H * W, (unsigned)C * hw4);
+    const unsigned hw4 = (unsigned)H * W * IES, hwo = (unsigned)H * W * OES;
+    const rsrc_t rin = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (long)b * C * H * W * IES), (unsigned)C * hw4);
+    const rsrc_t rout = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(out) + (long)b * C * H * W * OES), (unsigned)C * hwo);
 
     float wa0[9], wb0[9], wa1[9], wb1[9];                   // scalar loads, requested ahead of the halo so both latencies overlap
 #pragma unroll
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
         // instead of 9, and a wave touches 1 KB contiguous
         typedef float f4 __attribute__((ext_vector_type(4)));
         constexpr int NV = (TH + 2) * 16;                   // 544 float4 of the interior
-        f4 qa[3], qb[3], qc[3];
+        float qa[3][4], qb[3][4], qc[3][4];
         int qs[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -152,19 +153,20 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
             const int r = idx >> 4, c4 = idx & 15;
             const int y = ty0 - 1 + r, xx = tx0 + 4 * c4;
             const bool ok = idx < NV && y >= 0 && y < H && xx < W;
-            const unsigned g = ok ? (unsigned)(y * W + xx) * 4u : OOB;
+            const unsigned g = ok ? (unsigned)(y * W + xx) * IES : OOB;
             qs[i] = idx < NV ? r * LS + 1 + 4 * c4 : (TH + 2) * LS;        // spare cells (the 4 floats behind the tile)
-            qa[i] = bload4(rin, g, (unsigned)m * hw4);
-            qb[i] = bload4(rin, g, (unsigned)cb0 * hw4);
-            qc[i] = same ? f4{0.f, 0.f, 0.f, 0.f} : bload4(rin, g, (unsigned)cb1 * hw4);
+            st_load4<IBF>(qa[i], rin, g, (unsigned)m * hw4);
+            st_load4<IBF>(qb[i], rin, g, (unsigned)cb0 * hw4);
+            if (same) { qc[i][0] = qc[i][1] = qc[i][2] = qc[i][3] = 0.f; }
+            else st_load4<IBF>(qc[i], rin, g, (unsigned)cb1 * hw4);
         }
         const int er = threadIdx.x >> 1, ec = (threadIdx.x & 1) ? TW + 1 : 0;     // edge columns: threads 0..67
         const int ey = ty0 - 1 + er, ex = tx0 - 1 + ec;
         const bool eok = threadIdx.x < 2 * (TH + 2) && ey >= 0 && ey < H && ex >= 0 && ex < W;
-        const unsigned eg = eok ? (unsigned)(ey * W + ex) * 4u : OOB;
+        const unsigned eg = eok ? (unsigned)(ey * W + ex) * IES : OOB;
         const int es = threadIdx.x < 2 * (TH + 2) ? er * LS + ec : (TH + 2) * LS;
-        const float ea = bload(rin, eg, (unsigned)m * hw4), eb = bload(rin, eg, (unsigned)cb0 * hw4);
-        const float ecv = same ? 0.f : bload(rin, eg, (unsigned)cb1 * hw4);
+        const float ea = st_load1<IBF>(rin, eg, (unsigned)m * hw4), eb = st_load1<IBF>(rin, eg, (unsigned)cb0 * hw4);
+        const float ecv = same ? 0.f : st_load1<IBF>(rin, eg, (unsigned)cb1 * hw4);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -185,11 +187,11 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
         const int r = idx / LW, c = idx - r * LW;
         const int y = ty0 - 1 + r, xx = tx0 - 1 + c;
         const bool ok = idx < HALO && y >= 0 && y < H && xx >= 0 && xx < W;
-        const unsigned g = ok ? (unsigned)(y * W + xx) * 4u : OOB;
+        const unsigned g = ok ? (unsigned)(y * W + xx) * IES : OOB;
         slot[i] = idx < HALO ? r * LS + c : (TH + 2) * LS;     // spare cell: stores stay unconditional (no sunk load)
-        va[i] = bload(rin, g, (unsigned)m * hw4);
-        vb[i] = bload(rin, g, (unsigned)cb0 * hw4);
-        vc[i] = same ? 0.f : bload(rin, g, (unsigned)cb1 * hw4);
+        va[i] = st_load1<IBF>(rin, g, (unsigned)m * hw4);
+        vb[i] = st_load1<IBF>(rin, g, (unsigned)cb0 * hw4);
+        vc[i] = same ? 0.f : st_load1<IBF>(rin, g, (unsigned)cb1 * hw4);
     }
 #pragma unroll
     for (int i = 0; i < HPT; ++i) {
@@ -202,13 +204,13 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
     const int cx = threadIdx.x & 63;
     const int r0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 8;
     const int gx = tx0 + cx, gy0 = ty0 + r0;
-    const unsigned voff0 = (gx < W && gy0 < H) ? (unsigned)(gy0 * W + gx) * 4u : OOB;
+    const unsigned voff0 = (gx < W && gy0 < H) ? (unsigned)(gy0 * W + gx) * OES : OOB;
     const int rows_ok = H - gy0;                              // rows of this wave inside the image (>= 8: all)
-    const unsigned row4 = (unsigned)W * 4u;
+    const unsigned row4 = (unsigned)W * OES;
     if (same)
-        dw_gate_rows<true>(ta, tb[0], tb[0], wa0, wb0, wa1, wb1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hw4, (unsigned)j1 * hw4);
+        dw_gate_rows<true, OBF>(ta, tb[0], tb[0], wa0, wb0, wa1, wb1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hwo, (unsigned)j1 * hwo);
     else
-        dw_gate_rows<false>(ta, tb[0], tb[1], wa0, wb0, wa1, wb1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hw4, (unsigned)j1 * hw4);
+        dw_gate_rows<false, OBF>(ta, tb[0], tb[1], wa0, wb0, wa1, wb1, has1, r0, cx, rout, voff0, row4, rows_ok, (unsigned)j0 * hwo, (unsigned)j1 * hwo);
 }
 
 // mul/add maps: per output channel c:  sum_tap w3[c][tap] * (sum_i w1[c][i] * img[i][p+tap])
@@ -300,17 +302,29 @@ extern "C" int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, 
     return fdn_launch_status();
 }
 
-extern "C" int fdn_dwconv_gate(const float* x, const float* w, float* out, int B, int C, int H, int W, fdn_stream_t stream) {
+extern "C" int fdn_dwconv_gate(const void* x_, const float* w, void* out_, int B, int C, int H, int W, int x_bf16, int out_bf16,
+                               fdn_stream_t stream) {
+    const float* x = static_cast<const float*>(x_);
+    float* out = static_cast<float*>(out_);
     FDN_CHECK_ARG(x && w && out && B > 0 && C > 0 && H > 0 && W > 0 && C < 65536 && B < 65536);
     FDN_CHECK_ARG(4ull * C * H * W < 0x80000000ull);          // one image's C planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     const bool v4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    if (v4)
-        hipLaunchKernelGGL(dw_gate_kernel<true>, dim3(tx * ty, (C + 1) / 2, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, out,
-                           C, H, W, tx);
-    else
-        hipLaunchKernelGGL(dw_gate_kernel<false>, dim3(tx * ty, (C + 1) / 2, B), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, out,
-                           C, H, W, tx);
+    const dim3 grid(tx * ty, (C + 1) / 2, B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define FDN_GATE(V, I, O) hipLaunchKernelGGL((dw_gate_kernel<V, I, O>), grid, dim3(256), 0, s, x, w, out, C, H, W, tx)
+    if (v4) {
+        if (x_bf16 && out_bf16) FDN_GATE(true, true, true);
+        else if (x_bf16) FDN_GATE(true, true, false);
+        else if (out_bf16) FDN_GATE(true, false, true);
+        else FDN_GATE(true, false, false);
+    } else {
+        if (x_bf16 && out_bf16) FDN_GATE(false, true, true);
+        else if (x_bf16) FDN_GATE(false, true, false);
+        else if (out_bf16) FDN_GATE(false, false, true);
+        else FDN_GATE(false, false, false);
+    }
+#undef FDN_GATE
     return fdn_launch_status();
 }
 

@@ -177,8 +177,6 @@ __global__ __launch_bounds__(NW * 64, SH <= 19 ? 2 : 1) void fdsa_out_kernel(FoA
     }
 }
 
-int g_cus = 0;
-
 // 8-byte-lane form for level 1 (E <= 38, N <= 32, P % 4 == 0): a lane owns two consecutive pixels, so every load / store
 // moves 8 bytes per lane (the dword form stops at ~3.2 TB/s).  To stay within two waves per SIMD the three LayerNorm
 // groups are taken one after the other - v_value stays in registers, out_g is loaded (the next group while this one is
@@ -196,7 +194,15 @@ __device__ __forceinline__ void bstore2(f32x2 v, rsrc_t r, unsigned voff, unsign
 
 // DB: prefetch the next group into a second register set (level 1); without it the other wave on the SIMD covers the
 // load latency (level 2: 76-channel groups, two 32-row tiles - a second set would not leave two waves per SIMD).
-template <int SH, int MT, bool DB>
+template <bool BF>
+__device__ __forceinline__ f32x2 oload2(rsrc_t r, unsigned voff, unsigned soff) {      // two pixels of an `o` plane (fp32 or bf16 storage)
+    float v[2];
+    st_load2<BF>(v, r, voff, soff);
+    return f32x2{v[0], v[1]};
+}
+
+// IBF: the (out1|out2|out3|v_value) planes are stored as bf16 (written so by fdn_fdsa_fused); statistics, products and the result stay fp32
+template <int SH, int MT, bool DB, bool IBF>
 __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int E2 = 2 * SH;
@@ -226,17 +232,19 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
         const unsigned p_ = (unsigned)(tile - b * a.tiles_per_img) * (NW * 64) + (wave * 32 + ln) * 2;
         const bool ok = p_ < P;                               // P % 2 == 0: a pixel pair is inside or outside as a whole
         const unsigned pix = ok ? p_ : P - 2;
-        const float* ob = a.o + (long)b * 4 * E * P;
-        const rsrc_t rg[3] = {mk_rsrc(ob, (unsigned)E * P4), mk_rsrc(ob + (long)E * P, (unsigned)E * P4),
-                              mk_rsrc(ob + (long)2 * E * P, (unsigned)E * P4)};
-        const rsrc_t rv = mk_rsrc(ob + (long)3 * E * P, (unsigned)E * P4);
-        const unsigned voff = (kh * P + pix) * 4u;           // channel e = 2s + kh; e >= E reads 0 (outside the descriptor)
+        constexpr unsigned IES = st_bytes<IBF>();
+        const unsigned PI = P * IES;                          // bytes per `o` plane
+        const char* ob = reinterpret_cast<const char*>(a.o) + (long)b * 4 * E * P * IES;
+        auto oplanes = [&](int g) { return mk_rsrc(reinterpret_cast<const float*>(ob + (long)g * E * P * IES), (unsigned)E * PI); };
+        const rsrc_t rg[3] = {oplanes(0), oplanes(1), oplanes(2)};
+        const rsrc_t rv = oplanes(3);
+        const unsigned voff = (kh * P + pix) * IES;          // channel e = 2s + kh; e >= E reads 0 (outside the descriptor)
 
         f32x2 vv[SH], oa[SH], ob2[DB ? SH : 1];
 #pragma unroll
         for (int s = 0; s < SH; ++s) {
-            vv[s] = bload2(rv, voff, (unsigned)(2 * s) * P4);
-            oa[s] = bload2(rg[0], voff, (unsigned)(2 * s) * P4);
+            vv[s] = oload2<IBF>(rv, voff, (unsigned)(2 * s) * PI);
+            oa[s] = oload2<IBF>(rg[0], voff, (unsigned)(2 * s) * PI);
         }
         const unsigned nb4 = (unsigned)N * P4;
         const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             if (DB && g < 2) {
                 f32x2* nxt = (g & 1) ? oa : ob2;
 #pragma unroll
-                for (int s = 0; s < SH; ++s) nxt[s] = bload2(rg[g + 1], voff, (unsigned)(2 * s) * P4);
+                for (int s = 0; s < SH; ++s) nxt[s] = oload2<IBF>(rg[g + 1], voff, (unsigned)(2 * s) * PI);
             }
             // LayerNorm statistics of this group from registers (two-pass; lanes l and l^32 split the channels)
             f32x2 m = 0.f;
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             }
             if (!DB && g < 2) {
 #pragma unroll
-                for (int s = 0; s < SH; ++s) oa[s] = bload2(rg[g + 1], voff, (unsigned)(2 * s) * P4);
+                for (int s = 0; s < SH; ++s) oa[s] = oload2<IBF>(rg[g + 1], voff, (unsigned)(2 * s) * PI);
             }
         }
         // ---- epilogue: residual (one batch), store, next LayerNorm's statistics -------------------------------------
@@ -346,45 +354,29 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
     }
 }
 
-int g_cus_v = 0;
-template <int SH, int MT, bool DB>
+template <int SH, int MT, bool DB, bool IBF>
 int launch_vec(FoArgs a, hipStream_t s) {
     const size_t lds = (6UL * 2 * SH + 3UL * 2 * SH * (MT * 32 + 1)) * sizeof(float);
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fdsa_out_vec_kernel<SH, MT, DB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return FDN_ERR_LAUNCH;
-        attr = true;
-    }
-    if (g_cus_v == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_cus_v = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int cus = fdn_device_cus();
+    if (cus <= 0) return FDN_ERR_LAUNCH;
+    if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(fdsa_out_vec_kernel<SH, MT, DB, IBF>), lds)) return FDN_ERR_LAUNCH;
     a.tiles_per_img = cdiv(a.P, NW * 64);
     a.total_tiles = a.B * a.tiles_per_img;
-    int grid = g_cus_v * 2;
+    int grid = cus * 2;
     if (grid > a.total_tiles) grid = a.total_tiles;
-    hipLaunchKernelGGL((fdsa_out_vec_kernel<SH, MT, DB>), dim3(grid), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((fdsa_out_vec_kernel<SH, MT, DB, IBF>), dim3(grid), dim3(NW * 64), lds, s, a);
     return fdn_launch_status();
 }
 
 template <int SH, int MT>
 int launch(FoArgs a, hipStream_t s) {
     const size_t lds = (6UL * 2 * SH + 3UL * 2 * SH * (MT * 32 + 1)) * sizeof(float);
-    if (g_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int g_cus = fdn_device_cus();
+    if (g_cus <= 0) return FDN_ERR_LAUNCH;
     a.tiles_per_img = cdiv(a.P, NW * 32);
     a.total_tiles = a.B * a.tiles_per_img;
     auto kern = fdsa_out_kernel<SH, MT>;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return FDN_ERR_LAUNCH;
+    if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return FDN_ERR_LAUNCH;
     int per_cu = (int)((160 * 1024) / lds);
     const int want = SH <= 19 ? 2 : 1;
     if (per_cu > want) per_cu = want;
@@ -397,8 +389,9 @@ int launch(FoArgs a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int fdn_fdsa_out(const float* o, const float* w, const float* gamma3, const float* beta3, const float* res,
-                            float* out, float* stats_out, int B, int E, int N, int P, fdn_stream_t stream) {
+extern "C" int fdn_fdsa_out(const void* o_, const float* w, const float* gamma3, const float* beta3, const float* res,
+                            float* out, float* stats_out, int B, int E, int N, int P, int o_bf16, fdn_stream_t stream) {
+    const float* o = static_cast<const float*>(o_);
     FDN_CHECK_ARG(o && w && gamma3 && beta3 && out && B > 0 && E > 0 && N > 0 && P > 0);
     if ((unsigned long long)(4 * E + 2) * 4ull * P > 0xFFFFFFFFull || (unsigned long long)(N + 40) * 4ull * P > 0xFFFFFFFFull)
         return FDN_ERR_UNSUPPORTED;
@@ -408,12 +401,16 @@ extern "C" int fdn_fdsa_out(const float* o, const float* w, const float* gamma3,
     a.tiles_per_img = a.total_tiles = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int sh = (E + 1) / 2, mt = (N + 31) / 32;
-    static const bool novec = getenv("FDN_FO_NOVEC") != nullptr, novec2 = getenv("FDN_FO_NOVEC2") != nullptr;      // A/B switches
-    const bool vec_ok = P % 4 == 0 && !novec &&
+    const bool vec_ok = P % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |
           reinterpret_cast<uintptr_t>(stats_out)) & 15) == 0;
-    if (vec_ok && sh <= 19 && mt == 1) return launch_vec<19, 1, true>(a, s);       // level 1, 8-byte lanes
-    if (vec_ok && sh <= 38 && mt <= 2 && !novec2) return launch_vec<38, 2, false>(a, s);       // level 2
+    if (o_bf16) {                                               // bf16 storage exists in the pixel-pair form only
+        if (vec_ok && sh <= 19 && mt == 1) return launch_vec<19, 1, true, true>(a, s);
+        if (vec_ok && sh <= 38 && mt <= 2) return launch_vec<38, 2, false, true>(a, s);
+        return FDN_ERR_UNSUPPORTED;
+    }
+    if (vec_ok && sh <= 19 && mt == 1) return launch_vec<19, 1, true, false>(a, s);       // level 1, 8-byte lanes
+    if (vec_ok && sh <= 38 && mt <= 2) return launch_vec<38, 2, false, false>(a, s);       // level 2
     if (sh <= 19 && mt == 1) return launch<19, 1>(a, s);       // level 1: E = 38, C = 32
     if (sh <= 38 && mt <= 2) return launch<38, 2>(a, s);       // level 2: E = 76, C = 64 (one wave per SIMD, 490 registers: 1.74 vs 1.88 ms)
     return FDN_ERR_UNSUPPORTED;                                  // caller falls back to stats + conv1x1

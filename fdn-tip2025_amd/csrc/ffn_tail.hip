@@ -210,16 +210,10 @@ __global__ __launch_bounds__(NT) void ffn_tail_kernel(FtArgs a) {
     }
 }
 
-int g_cus = 0;
-
 template <int MT>
 int launch(FtArgs a, hipStream_t s) {
-    if (g_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int g_cus = fdn_device_cus();
+    if (g_cus <= 0) return FDN_ERR_LAUNCH;
     a.tiles_x = cdiv(a.W, TC);
     a.tiles_per_img = a.tiles_x * cdiv(a.H, TR);
     a.total_tiles = a.B * a.tiles_per_img;

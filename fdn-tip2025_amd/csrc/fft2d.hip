@@ -819,11 +819,7 @@ int pick_tc(int H) {
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
-            hipSuccess)
-            return FDN_ERR_LAUNCH;
-    }
+    if (bytes > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kernel), bytes)) return FDN_ERR_LAUNCH;
     return FDN_OK;
 }
 

@@ -567,14 +567,44 @@ __device__ __forceinline__ void bstorev(typename VecT<VEC>::type f, rsrc_t r, un
     else __builtin_amdgcn_raw_buffer_store_b64(u, r, voff, soff, 0);
 }
 
-template <int NCH, int PRO, int VEC, bool TAIL>
+// the same for an activation tensor kept in bf16 STORAGE (BF = true: VEC bf16 values = VEC * 2 bytes per lane, widened to fp32 /
+// rounded to nearest-even; the arithmetic is fp32 either way)
+template <int VEC, bool BF>
+__device__ __forceinline__ typename VecT<VEC>::type sloadv(rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (!BF) return bloadv<VEC>(r, voff, soff);
+    else {
+        static_assert(VEC == 2, "bf16 storage: pixel pairs");
+        float v[2];
+        st_load2<true>(v, r, voff, soff);
+        typename VecT<VEC>::type f;
+        f[0] = v[0];
+        f[1] = v[1];
+        return f;
+    }
+}
+template <int VEC, bool BF>
+__device__ __forceinline__ void sstorev(typename VecT<VEC>::type f, rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (!BF) bstorev<VEC>(f, r, voff, soff);
+    else {
+        static_assert(VEC == 2, "bf16 storage: pixel pairs");
+        const float v[2] = {f[0], f[1]};
+        st_store2<true>(v, r, voff, soff);
+    }
+}
+__device__ __forceinline__ const float* byte_advance(const float* p, long bytes) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + bytes);
+}
+
+// XBF: x[0] is stored as bf16; OBF: out is stored as bf16 (non-TAIL form).  Statistics, residual and TAIL output stay fp32.
+template <int NCH, int PRO, int VEC, bool TAIL, bool XBF = false, bool OBF = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef typename VecT<VEC>::type vf;
     constexpr int NT = 256, NWV = 4;
     constexpr int Kp = NCH * KC, KS = NCH * 16;
+    constexpr unsigned XES = st_bytes<XBF>(), OES = st_bytes<OBF>();
     const int K = d.K, N = d.N;
-    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u, PX = P * XES, PO = P * OES;
     const int ntiles = (N + 31) / 32;
     const int NS = ntiles * 32 + 1;
     float* tg = smem;
@@ -620,10 +650,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
     bool live = tile < g.total_tiles;
     Tile cur = tile_setup(live ? tile : 0);
     if (live) {
-        const rsrc_t r0 = mk_rsrc(d.x[0] + (long)cur.b * d.xbs[0], (unsigned)K * P4);
-        const unsigned voff = (kh * P + cur.pix) * 4u;
+        const rsrc_t r0 = mk_rsrc(byte_advance(d.x[0], (long)cur.b * d.xbs[0] * XES), (unsigned)K * PX);
+        const unsigned voff = (kh * P + cur.pix) * XES;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xa[s] = bloadv<VEC>(r0, voff, (unsigned)(2 * s) * P4);      // k >= K reads 0
+        for (int s = 0; s < KS; ++s) xa[s] = sloadv<VEC, XBF>(r0, voff, (unsigned)(2 * s) * PX);      // k >= K reads 0
         stats_issue(cur);
     }
     while (live) {
@@ -638,12 +668,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
         const int ntile = tile + gridDim.x;
         const bool nlive = ntile < g.total_tiles;
         const Tile nxt = tile_setup(nlive ? ntile : tile);
-        const rsrc_t rn = mk_rsrc(d.x[0] + (long)nxt.b * d.xbs[0], (unsigned)K * P4);
-        const unsigned voffn = (kh * P + nxt.pix) * 4u;
+        const rsrc_t rn = mk_rsrc(byte_advance(d.x[0], (long)nxt.b * d.xbs[0] * XES), (unsigned)K * PX);
+        const unsigned voffn = (kh * P + nxt.pix) * XES;
         if (nlive) stats_issue(nxt);                               // (mu, rstd) of the next tile: consumed after this one
 
-        const rsrc_t ro = mk_rsrc(d.out + (long)cur.b * d.obs, (unsigned)N * P4);
-        const unsigned voff = cur.ok ? (4u * kh * P + cur.pix) * 4u : 0x80000000u;     // outside pixels: stores dropped
+        const rsrc_t ro = mk_rsrc(byte_advance(d.out, (long)cur.b * d.obs * OES), (unsigned)N * PO);
+        const unsigned voff = cur.ok ? (4u * kh * P + cur.pix) * 4u : 0x80000000u;     // outside pixels: stores dropped (fp32 operands)
+        const unsigned voffo = cur.ok ? (4u * kh * P + cur.pix) * OES : 0x80000000u;   // the same in bytes of the output's storage type
         for (int m = 0; m < ntiles; ++m) {
             const bool refill = nlive && m == ntiles - 1;
             f32x16 acc[VEC];
@@ -678,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                         acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][i], xa[grp * 8 + i][v], acc[v], 0, 0, 0);
                 if (refill) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) xa[grp * 8 + i] = bloadv<VEC>(rn, voffn, (unsigned)(2 * (grp * 8 + i)) * P4);
+                    for (int i = 0; i < 8; ++i) xa[grp * 8 + i] = sloadv<VEC, XBF>(rn, voffn, (unsigned)(2 * (grp * 8 + i)) * PX);
                 }
             }
             auto epilogue = [&](auto act_c, auto epi_c) __attribute__((always_inline)) {
@@ -693,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_
                     o += bl[nrow + 4 * kh];
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o[v] = apply_act(o[v], act_);
-                    bstorev<VEC>(o, ro, voff, (unsigned)nrow * P4);        // rows >= N fall outside the descriptor
+                    sstorev<VEC, OBF>(o, ro, voffo, (unsigned)nrow * PO);        // rows >= N fall outside the descriptor
                 }
             } else {
                 // TAIL (N <= 32, the narrow project_out convs): residual as one batch of vector loads, then the stores and
@@ -1029,10 +1060,11 @@ __global__ __launch_bounds__(512) void conv1x1_smallk_stream_vec_kernel(fdn_conv
 // a lane owns two consecutive pixels, so each A operand read from LDS feeds two MFMA chains per output tile and every
 // load / store moves 8 bytes per lane.  One input segment, no prologue, residual or no epilogue operand, statistics
 // of the result when N fits one pass.  Weights resident in LDS or double-buffered per 32-deep chunk, as the generic kernel.
-template <int MT>
+template <int MT, bool XBF = false>          // XBF: x[0] is stored as bf16
 __global__ __launch_bounds__(256, 2) void conv1x1_kstream_vec_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int VEC = 2, NW = 4, NT = NW * 64;
+    constexpr unsigned XES = st_bytes<XBF>();
     typedef typename VecT<VEC>::type vf;
     constexpr int WS = MT * 32 + 1;
     constexpr int CH = KC * WS;
@@ -1078,10 +1110,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kstream_vec_kernel(fdn_conv1x1
     };
     vf xa[16], xb[16];
     auto x_issue = [&](const Tile& t, int c_, vf (&xv)[16]) {
-        const rsrc_t r0 = mk_rsrc(d.x[0] + (long)t.b * d.xbs[0], (unsigned)K * P4);
-        const unsigned voff = (kh * P + t.pix) * 4u;
+        const rsrc_t r0 = mk_rsrc(byte_advance(d.x[0], (long)t.b * d.xbs[0] * XES), (unsigned)K * P * XES);
+        const unsigned voff = (kh * P + t.pix) * XES;
 #pragma unroll
-        for (int s_ = 0; s_ < 16; ++s_) xv[s_] = bloadv<VEC>(r0, voff, (unsigned)(c_ * KC + 2 * s_) * P4);   // k >= K reads 0
+        for (int s_ = 0; s_ < 16; ++s_) xv[s_] = sloadv<VEC, XBF>(r0, voff, (unsigned)(c_ * KC + 2 * s_) * P * XES);   // k >= K reads 0
     };
     f32x16 acc[MT][VEC];
 #pragma unroll
@@ -1206,7 +1238,10 @@ int pick_mt(int N) {
     return best;
 }
 
-int g_num_cu = 0;
+// launch-time facts are cached per (kernel, device) in capi.hip: no occupancy / attribute query on the hot path
+#define FDN_NUM_CU_OR_FAIL()               \
+    const int g_num_cu = fdn_device_cus(); \
+    if (g_num_cu <= 0) return FDN_ERR_LAUNCH;
 
 template <int MT, int PRO, int NW, bool EARLY>
 int launch(const fdn_conv1x1_desc& d, hipStream_t s) {
@@ -1221,20 +1256,11 @@ int launch(const fdn_conv1x1_desc& d, hipStream_t s) {
     g.tiles_per_img = cdiv(d.P, NW * 32);
     g.total_tiles = d.B * g.tiles_per_img;
     auto kern = conv1x1_kernel<MT, PRO, NW, EARLY>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return FDN_ERR_LAUNCH;
-    }
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return FDN_ERR_LAUNCH;
+    FDN_NUM_CU_OR_FAIL()
     // persistent grid: as many workgroups as can be co-resident (LDS / register limited), capped by the work
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NW * 64, lds) != hipSuccess) per_cu = 1;
+    if (!fdn_occupancy(&per_cu, reinterpret_cast<const void*>(kern), NW * 64, lds)) per_cu = 1;
     if (per_cu * NW > 16) per_cu = 16 / NW;                     // 4 waves per SIMD are enough to hide the loads
     if (per_cu < 1) per_cu = 1;
     int grid = g_num_cu * per_cu;
@@ -1247,23 +1273,14 @@ template <int NCH, int PRO>
 int launch_smallk(const fdn_conv1x1_desc& d, hipStream_t s) {
     const int ntiles = (d.N + 31) / 32;
     const size_t lds = (2UL * NCH * KC + (size_t)NCH * KC * (ntiles * 32 + 1) + ntiles * 32) * sizeof(float);
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    FDN_NUM_CU_OR_FAIL()
     constexpr int NW = 8;
     Geo g;
     g.resident = 1;
     g.tiles_per_img = cdiv(d.P, NW * 32);
     g.total_tiles = d.B * g.tiles_per_img;
     auto kern = conv1x1_smallk_kernel<NCH, PRO, NW>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return FDN_ERR_LAUNCH;
-    }
+    if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return FDN_ERR_LAUNCH;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 3) per_cu = 3;
     if (per_cu < 1) per_cu = 1;
@@ -1277,12 +1294,7 @@ template <int NCH, int PRO>
 int launch_smallk_stream(const fdn_conv1x1_desc& d, hipStream_t s) {
     constexpr int NW = 8;
     const size_t lds = (2UL * NCH * KC + 2UL * NCH * KC * 33 + ((d.N + 31) / 32) * 32) * sizeof(float);
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    FDN_NUM_CU_OR_FAIL()
     Geo g;
     g.resident = 0;
     g.tiles_per_img = cdiv(d.P, NW * 32);
@@ -1293,28 +1305,19 @@ int launch_smallk_stream(const fdn_conv1x1_desc& d, hipStream_t s) {
     return fdn_launch_status();
 }
 
-template <int NCH, int PRO, int VEC, bool TAIL = false>
+template <int NCH, int PRO, int VEC, bool TAIL = false, bool XBF = false, bool OBF = false>
 int launch_smallk_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
     const int ntiles = (d.N + 31) / 32;
     const size_t lds = (2UL * NCH * KC + (size_t)NCH * KC * (ntiles * 32 + 1) + ntiles * 32) * sizeof(float);
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    FDN_NUM_CU_OR_FAIL()
     Geo g;
     g.resident = 1;
     g.tiles_per_img = cdiv(d.P, 4 * 32 * VEC);
     g.total_tiles = d.B * g.tiles_per_img;
-    auto kern = conv1x1_smallk_vec_kernel<NCH, PRO, VEC, TAIL>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess)
-            return FDN_ERR_LAUNCH;
-    }
+    auto kern = conv1x1_smallk_vec_kernel<NCH, PRO, VEC, TAIL, XBF, OBF>;
+    if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return FDN_ERR_LAUNCH;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1)
+    if (!fdn_occupancy(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) || per_cu < 1)
         per_cu = 1;
     if (per_cu > 4) per_cu = 4;
     int grid = g_num_cu * per_cu;
@@ -1336,12 +1339,7 @@ bool smallk_vec_ok(const fdn_conv1x1_desc& d) {
 template <int NCH, int PRO>
 int launch_smallk_stream_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
     const size_t lds = (2UL * NCH * KC + 2UL * NCH * KC * 33 + ((d.N + 31) / 32) * 32) * sizeof(float);
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    FDN_NUM_CU_OR_FAIL()
     Geo g;
     g.resident = 0;
     g.tiles_per_img = cdiv(d.P, 8 * 32 * 2);
@@ -1352,7 +1350,7 @@ int launch_smallk_stream_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
     return fdn_launch_status();
 }
 
-template <int MT>
+template <int MT, bool XBF = false>
 int launch_kstream_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
     const int nch = (d.K + KC - 1) / KC;
     const size_t chunk = (size_t)KC * (MT * 32 + 1) * sizeof(float);
@@ -1363,18 +1361,11 @@ int launch_kstream_vec(const fdn_conv1x1_desc& d, hipStream_t s) {
     lds += (size_t)MT * 32 * sizeof(float);
     g.tiles_per_img = cdiv(d.P, 4 * 32 * 2);
     g.total_tiles = d.B * g.tiles_per_img;
-    auto kern = conv1x1_kstream_vec_kernel<MT>;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return FDN_ERR_LAUNCH;
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FDN_ERR_LAUNCH;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    auto kern = conv1x1_kstream_vec_kernel<MT, XBF>;
+    if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return FDN_ERR_LAUNCH;
+    FDN_NUM_CU_OR_FAIL()
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1)
+    if (!fdn_occupancy(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) || per_cu < 1)
         per_cu = 1;
     if (per_cu > 4) per_cu = 4;
     int grid = g_num_cu * per_cu;
@@ -1486,6 +1477,38 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         if (d.kseg[1] > 0 && ((d.kseg[0] & 1) || (d.kseg[1] & 1))) return FDN_ERR_UNSUPPORTED;   // k-step pairs must not straddle segments
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // bf16 STORAGE of one operand (the block-internal FDFFN tensors of levels 1-2): the pixel-pair kernels only -
+    //   x_bf16  : the project_out convs (narrow TAIL form / K-streaming form), fp32 result;
+    //   out_bf16: the project_in convs (small-K form, plain or LayerNorm prologue), fp32 input.
+    if (d.x_bf16 || d.out_bf16) {
+        if (d.x_bf16 && d.out_bf16) return FDN_ERR_UNSUPPORTED;
+        if (d.x_bf16) {
+            if (kstream_vec_ok(d)) {
+                const int tiles = (d.N + 31) / 32;
+                if (tiles == 1) return launch_kstream_vec<1, true>(d, s);
+                if (tiles == 2) return launch_kstream_vec<2, true>(d, s);
+                return launch_kstream_vec<3, true>(d, s);
+            }
+            if (narrow_vec_ok(d)) {
+                if (d.K <= KC) return launch_smallk_vec<1, FDN_PRO_NONE, 2, true, true, false>(d, s);
+                if (d.K <= 2 * KC) return launch_smallk_vec<2, FDN_PRO_NONE, 2, true, true, false>(d, s);
+                return launch_smallk_vec<3, FDN_PRO_NONE, 2, true, true, false>(d, s);
+            }
+            return FDN_ERR_UNSUPPORTED;
+        }
+        if (smallk_ok(d) && smallk_vec_ok(d)) {
+            const int ntiles = (d.N + 31) / 32;
+            if (d.K <= KC) {
+                if (d.pro == FDN_PRO_LN) return launch_smallk_vec<1, FDN_PRO_LN, 2, false, false, true>(d, s);
+                return launch_smallk_vec<1, FDN_PRO_NONE, 2, false, false, true>(d, s);
+            }
+            if ((2UL * 2 * KC + 2UL * KC * (ntiles * 32 + 1)) * sizeof(float) <= 52 * 1024) {
+                if (d.pro == FDN_PRO_LN) return launch_smallk_vec<2, FDN_PRO_LN, 2, false, false, true>(d, s);
+                return launch_smallk_vec<2, FDN_PRO_NONE, 2, false, false, true>(d, s);
+            }
+        }
+        return FDN_ERR_UNSUPPORTED;
+    }
     // K = 64 with a weight matrix too big to sit in LDS three times per CU (level-2 to_hidden, 64 -> 304): stream the weights too
     if (d.K > KC && d.K <= 2 * KC && d.N >= 256 && !d.stats_out && d.kseg[1] == 0 && d.epi == FDN_EPI_NONE &&
         (d.pro == FDN_PRO_NONE || d.pro == FDN_PRO_LN) && smallk_vec_ok(d)) {               // 15.1 -> 12.4 ms

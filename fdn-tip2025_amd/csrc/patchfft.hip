@@ -14,7 +14,10 @@ namespace {
 
 constexpr int TH = 32, TW = 64;
 constexpr int NP = 32;             // patches per tile
-constexpr int PS = 41;             // patch stride of the spectrum buffer in float2 (40 used + 1 pad)
+constexpr int KXS = 9;             // stride between the kx columns of a patch spectrum, in float2 (8 used + 1 pad)
+constexpr int PS = 5 * KXS;        // patch stride: column-phase thread t = 5 * patch + kx sits at 9 t float2 = 18 t dwords, so the
+                                   // 8-byte accesses of 16 / 32 consecutive threads fall into distinct banks (with 8 / 41 the kx = 0
+                                   // and kx = 4 columns of a patch shared their banks: 2-3x the LDS cycles in the column phase)
 constexpr float C8 = 0.70710678118654752440f;
 
 // in-place 8-point complex FFT, natural order in and out.  INV: e^{+...}, unscaled.
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
             float2 sp[5];
             rfft8_row(o8, sp);
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) S[(t * NP + patch) * PS + kx * 8 + rr] = sp[kx];
+            for (int kx = 0; kx < 5; ++kx) S[(t * NP + patch) * PS + kx * KXS + rr] = sp[kx];
             stash(halo[(t + 1) & 1]);
         } else {                                                            // v_value goes straight out
             bstore8(o8, rout, ooff, (unsigned)(3 * E + e) * hw4);
@@ -291,9 +294,9 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
         float2 q[8], k[8], v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            q[i] = S[(0 * NP + pj) * PS + kx * 8 + i];
-            k[i] = S[(1 * NP + pj) * PS + kx * 8 + i];
-            v[i] = S[(2 * NP + pj) * PS + kx * 8 + i];
+            q[i] = S[(0 * NP + pj) * PS + kx * KXS + i];
+            k[i] = S[(1 * NP + pj) * PS + kx * KXS + i];
+            v[i] = S[(2 * NP + pj) * PS + kx * KXS + i];
         }
         fft8<false>(q);
         fft8<false>(k);
@@ -323,9 +326,9 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
         constexpr float sc = 1.0f / 64.0f;   // norm='backward'
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            S[(0 * NP + pj) * PS + kx * 8 + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
-            S[(1 * NP + pj) * PS + kx * 8 + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
-            S[(2 * NP + pj) * PS + kx * 8 + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
+            S[(0 * NP + pj) * PS + kx * KXS + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
+            S[(1 * NP + pj) * PS + kx * KXS + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
+            S[(2 * NP + pj) * PS + kx * KXS + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
         }
     }
     __syncthreads();
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     for (int t = 0; t < 3; ++t) {
         float2 x[5];
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) x[kx] = S[(t * NP + patch) * PS + kx * 8 + rr];
+        for (int kx = 0; kx < 5; ++kx) x[kx] = S[(t * NP + patch) * PS + kx * KXS + rr];
         float r[8];
         irfft8_row(x, r);
         bstore8(r, rout, ooff, (unsigned)(t * E + e) * hw4);
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
             float2 o[5];
             rfft8_row(r, o);
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) S[patch * PS + kx * 8 + rr] = o[kx];
+            for (int kx = 0; kx < 5; ++kx) S[patch * PS + kx * KXS + rr] = o[kx];
         }
         __syncthreads();
 
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
             const int pj = tid / 5, kx = tid - pj * 5;
             float2 z[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) z[i] = S[pj * PS + kx * 8 + i];
+            for (int i = 0; i < 8; ++i) z[i] = S[pj * PS + kx * KXS + i];
             fft8<false>(z);
 #pragma unroll
             for (int ky = 0; ky < 8; ++ky)
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
             fft8<true>(z);
             constexpr float sc = 1.0f / 64.0f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) S[pj * PS + kx * 8 + i] = make_float2(z[i].x * sc, z[i].y * sc);
+            for (int i = 0; i < 8; ++i) S[pj * PS + kx * KXS + i] = make_float2(z[i].x * sc, z[i].y * sc);
         }
         __syncthreads();
 
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
         {
             float2 xk[5];
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) xk[kx] = S[patch * PS + kx * 8 + rr];
+            for (int kx = 0; kx < 5; ++kx) xk[kx] = S[patch * PS + kx * KXS + rr];
             float r[8];
             irfft8_row(xk, r);
 #pragma unroll
@@ -560,17 +563,19 @@ struct FusedArgs {
     long xbs;
     const float* stats;
     const float* wpk;
-    const float* bpk;
     const float* dww;
     const float* fftw;
     float* out;
     int E, H, W, tiles_x, tiles_per_img, nchunks;
+    int stagger_lo, stagger_hi;        // workgroups [lo, hi) start half a chunk late (see the kernel)
 };
 
 template <int C, bool LN, bool OBF>          // OBF: the (out1|out2|out3|v_value) planes are stored as bf16
 __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
-    __shared__ float hid[32 * FPL + 4];
+    __shared__ float hid[32 * FPL];
     __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
+    __shared__ float wks[32 * 9];                                     // depthwise taps of the chunk: [kind * 8 + channel][9]
+    __shared__ float fgs[FEG * 40];                                   // fft gains of the chunk's channels: [channel][ky][kx]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
     int t_ = blockIdx.x;
@@ -590,8 +595,8 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
 
     // ---- the wave's strips of the normalised halo tile: B operands, resident for the whole workgroup ----------
     float xs[3][C / 2];
+    float xone[3];                      // B operand of the bias k-step: 1 on k = 0 for pixels inside the image, else 0
     int pixoff[3];
-    bool pvalid[3];
 #pragma unroll
     for (int si = 0; si < 3; ++si) {
         const int s = wave + 4 * si;
@@ -600,8 +605,8 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
         const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
         const bool in_tile = s < FNS && p < FHP;
         const bool ok = in_tile && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        pvalid[si] = ok;
-        pixoff[si] = in_tile ? r * FRS + c : 32 * FPL;            // spare cells behind the planes
+        xone[si] = (ok && kh == 0) ? 1.f : 0.f;
+        pixoff[si] = in_tile ? r * FRS + c : FHW;                 // lanes past the tile: the unused pad cell of row 0 of each plane
         const unsigned g = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
         float mu = 0.f, rs = 1.f;
         if (LN) {
@@ -624,35 +629,52 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     const unsigned opix = gx0 < W ? (unsigned)((ty0 + row) * W + gx0) * OES : OOB;
     const float* hb = hid + el * FPL + row * FRS + px * 8;
 
+    // Per-chunk operands.  A operands (packed per chunk / k-step / lane by fdn_fdsa_pack, last k-step = the bias row against
+    // `xone`): registers, reloaded for the NEXT chunk right after this chunk's MFMAs so the loads fly during the spectral
+    // phases.  Depthwise taps and fft gains: one element per thread, staged through LDS a chunk ahead.
+    constexpr int KS = C / 2 + 1;
+    float aw[KS];
+    auto aw_fetch = [&](int ch) {
+        const float* wp = a.wpk + ((long)ch * KS) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) aw[j] = wp[j * 64];
+    };
+    float st_w = 0.f, st_w1 = 0.f, st_f0 = 0.f, st_f1 = 0.f;
+    auto stage_fetch = [&](int ch) {
+        auto tap_of = [&](int i) {                                      // element i < 288: row m = kind * 8 + channel, tap i % 9
+            const int m = i / 9, tap = i - m * 9;
+            const int ew = ch * FEG + (m & 7);
+            return a.dww[(long)((m >> 3) * E + (ew < E ? ew : E - 1)) * 9 + tap];
+        };
+        st_w = tap_of(tid);
+        st_w1 = tid < 32 ? tap_of(tid + 256) : 0.f;
+        const int c0 = tid / 40, c1 = (tid + 256) / 40;                 // gains: 320 values
+        const int e0_ = ch * FEG + c0, e1_ = ch * FEG + c1;
+        st_f0 = a.fftw[(e0_ < E ? e0_ : E - 1) * 40 + (tid - c0 * 40)];
+        st_f1 = (tid < 64) ? a.fftw[(e1_ < E ? e1_ : E - 1) * 40 + (tid + 256 - c1 * 40)] : 0.f;
+    };
+    auto stage_store = [&]() {
+        wks[tid] = st_w;
+        if (tid < 32) wks[tid + 256] = st_w1;
+        fgs[tid] = st_f0;
+        if (tid < 64) fgs[tid + 256] = st_f1;
+    };
+    aw_fetch(0);
+    stage_fetch(0);
+    stage_store();                      // (visible behind the first barrier of the loop)
+    // Two workgroups share a CU and would run their phases in lockstep (matrix cores busy while the vector ALUs idle, then
+    // the reverse): the second wave of workgroups the dispatcher hands out starts half a chunk late, and every later
+    // workgroup inherits the offset of the slot it takes over.
+    if ((int)blockIdx.x >= a.stagger_lo && (int)blockIdx.x < a.stagger_hi) {
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(64);
+    }
+
     for (int ch = 0; ch < a.nchunks; ++ch) {
         const int e0 = ch * FEG;
         const int e = e0 + el;
-        const int ec = e < E ? e : E - 1;
-        // ---- operands of this chunk: packed weights (coalesced), bias of this lane's 16 accumulator rows, stencil taps
-        float aw[C / 2];
-        {
-            const float* wp = a.wpk + ((long)ch * (C / 2)) * 64 + lane;
-#pragma unroll
-            for (int j = 0; j < C / 2; ++j) aw[j] = wp[j * 64];
-        }
-        float bv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = a.bpk[ch * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
-        float wk[4][9];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 9; ++i) wk[t][i] = a.dww[(long)(t * E + ec) * 9 + i];
-        float fg[8];
-        {
-            const int pjc = tid < NP * 5 ? tid / 5 : 0, kxc = tid < NP * 5 ? tid % 5 : 0;
-            const int eq = e0 + (pjc >> 2);
-            const int eqc = eq < E ? eq : E - 1;
-#pragma unroll
-            for (int ky = 0; ky < 8; ++ky) fg[ky] = a.fftw[(eqc * 8 + ky) * 5 + kxc];
-        }
-
-        // ---- to_hidden on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes ---------------------
+        // ---- to_hidden on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes (0 outside the image: the
+        // strip, its statistics and `xone` all read 0 there)
 #pragma unroll
         for (int si = 0; si < 3; ++si) {
             if (wave + 4 * si < FNS) {                              // wave-uniform
@@ -661,12 +683,15 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
                 for (int j = 0; j < C / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[j], xs[si][j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[C / 2], xone[si], acc, 0, 0, 0);      // + bias (fma(b, 1, acc) = acc + b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;           // row = kind * 8 + channel of the chunk
-                    hid[m * FPL + pixoff[si]] = pvalid[si] ? acc[r] + bv[r] : 0.f;
-                }
+                for (int r = 0; r < 16; ++r) hid[((r & 3) + 8 * (r >> 2) + 4 * kh) * FPL + pixoff[si]] = acc[r];   // row = kind * 8 + channel
             }
+        }
+        const bool more = ch + 1 < a.nchunks;                       // uniform
+        if (more) {
+            aw_fetch(ch + 1);
+            stage_fetch(ch + 1);
         }
         __syncthreads();
 
@@ -674,6 +699,9 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float* hp = hb + t * 8 * FPL;
+            float wkt[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wkt[i] = wks[(t * 8 + el) * 9 + i];
             float o8[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o8[j] = 0.f;
@@ -685,13 +713,13 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) o8[j] = fmaf(wk[t][dy * 3 + dx], v[j + dx], o8[j]);
+                    for (int dx = 0; dx < 3; ++dx) o8[j] = fmaf(wkt[dy * 3 + dx], v[j + dx], o8[j]);
             }
             if (t < 3) {
                 float2 sp[5];
                 rfft8_row(o8, sp);
 #pragma unroll
-                for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * 8 + row] = sp[kx];
+                for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * KXS + row] = sp[kx];
             } else {
                 st_store8<OBF>(o8, rout, e < E ? opix + (unsigned)(3 * E + e) * hwo : OOB, 0);
             }
@@ -704,10 +732,13 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
             float2 q[8], k[8], v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                q[i] = S[(0 * NP + pj) * PS + kx * 8 + i];
-                k[i] = S[(1 * NP + pj) * PS + kx * 8 + i];
-                v[i] = S[(2 * NP + pj) * PS + kx * 8 + i];
+                q[i] = S[(0 * NP + pj) * PS + kx * KXS + i];
+                k[i] = S[(1 * NP + pj) * PS + kx * KXS + i];
+                v[i] = S[(2 * NP + pj) * PS + kx * KXS + i];
             }
+            float fg[8];
+#pragma unroll
+            for (int ky = 0; ky < 8; ++ky) fg[ky] = fgs[(pj >> 2) * 40 + ky * 5 + kx];
             fft8<false>(q);
             fft8<false>(k);
             fft8<false>(v);
@@ -736,9 +767,9 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
             constexpr float sc = 1.0f / 64.0f;   // norm='backward'
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                S[(0 * NP + pj) * PS + kx * 8 + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
-                S[(1 * NP + pj) * PS + kx * 8 + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
-                S[(2 * NP + pj) * PS + kx * 8 + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
+                S[(0 * NP + pj) * PS + kx * KXS + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
+                S[(1 * NP + pj) * PS + kx * KXS + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
+                S[(2 * NP + pj) * PS + kx * KXS + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
             }
         }
         __syncthreads();
@@ -748,41 +779,41 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
         for (int t = 0; t < 3; ++t) {
             float2 xk[5];
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) xk[kx] = S[(t * NP + slot) * PS + kx * 8 + row];
+            for (int kx = 0; kx < 5; ++kx) xk[kx] = S[(t * NP + slot) * PS + kx * KXS + row];
             float r8[8];
             irfft8_row(xk, r8);
             st_store8<OBF>(r8, rout, e < E ? opix + (unsigned)(t * E + e) * hwo : OOB, 0);
         }
+        if (more) stage_store();        // taps (last read before the second barrier) and gains (before the third) of the next chunk
         // (the next chunk's MFMA phase writes `hid`, free since the second barrier; its row phase rewrites S behind
         //  the barrier that follows the MFMA phase, i.e. after every thread has finished these reads)
     }
 }
 
-// fdn_fdsa_pack: [4E][C] weights (+ LayerNorm gamma / beta of the input) -> per (chunk, k-step, lane) A operands
+// fdn_fdsa_pack: [4E][C] weights (+ LayerNorm gamma / beta of the input) -> per (chunk, k-step, lane) A operands; the last
+// k-step of a chunk carries the bias row (W beta, fp64 sum) on k = 0 and zeros on k = 1
 __global__ void fdsa_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 float* __restrict__ wpk, float* __restrict__ bpk, int C, int E, int nchunks) {
+                                 float* __restrict__ wpk, int C, int E, int nchunks) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nw = nchunks * (C / 2) * 64;
-    if (idx < nw) {
-        const int lane = idx & 63, j = (idx >> 6) % (C / 2), ch = (idx >> 6) / (C / 2);
-        const int m = lane & 31, k = 2 * j + (lane >> 5);
-        const int e = ch * FEG + (m & 7);
-        float v = 0.f;
-        if (e < E) {
-            v = w[(long)((m >> 3) * E + e) * C + k];
+    const int KS = C / 2 + 1;
+    if (idx >= nchunks * KS * 64) return;
+    const int lane = idx & 63, j = (idx >> 6) % KS, ch = (idx >> 6) / KS;
+    const int m = lane & 31, kh = lane >> 5;
+    const int e = ch * FEG + (m & 7);
+    float v = 0.f;
+    if (e < E) {
+        const float* wr = w + (long)((m >> 3) * E + e) * C;
+        if (j < C / 2) {
+            const int k = 2 * j + kh;
+            v = wr[k];
             if (gamma) v *= gamma[k];
+        } else if (kh == 0 && beta) {
+            double sacc = 0.0;
+            for (int k = 0; k < C; ++k) sacc += (double)wr[k] * (double)beta[k];
+            v = (float)sacc;
         }
-        wpk[idx] = v;
-    } else if (idx < nw + nchunks * 32) {
-        const int i = idx - nw, ch = i >> 5, m = i & 31;
-        const int e = ch * FEG + (m & 7);
-        double s = 0.0;
-        if (e < E && beta) {
-            const float* wr = w + (long)((m >> 3) * E + e) * C;
-            for (int k = 0; k < C; ++k) s += (double)wr[k] * (double)beta[k];
-        }
-        bpk[i] = (float)s;
     }
+    wpk[idx] = v;
 }
 
 }  // namespace
@@ -823,31 +854,34 @@ extern "C" int fdn_fdffn_mid(const void* x_, const float* w0, const float* w2, c
     return fdn_launch_status();
 }
 
-extern "C" int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, float* bpk, int C, int E,
-                             fdn_stream_t stream) {
-    FDN_CHECK_ARG(w && wpk && bpk && C > 0 && C % 2 == 0 && E > 0 && (!gamma == !beta));
+extern "C" int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, fdn_stream_t stream) {
+    FDN_CHECK_ARG(w && wpk && C > 0 && C % 2 == 0 && E > 0 && (!gamma == !beta));
     const int nch = (E + FEG - 1) / FEG;
-    const int total = nch * (C / 2) * 64 + nch * 32;
+    const int total = nch * (C / 2 + 1) * 64;
     hipLaunchKernelGGL(fdsa_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma, beta, wpk,
-                       bpk, C, E, nch);
+                       C, E, nch);
     return fdn_launch_status();
 }
 
-extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* bpk, const float* dw_w,
-                              const float* fft_w, void* out_, int B, int C, int E, int H, int W, int out_bf16, fdn_stream_t stream) {
+extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
+                              void* out_, int B, int C, int E, int H, int W, int out_bf16, fdn_stream_t stream) {
     float* out = static_cast<float*>(out_);
-    FDN_CHECK_ARG(x && wpk && bpk && dw_w && fft_w && out && B > 0 && E > 0 && H > 0 && W > 0);
+    FDN_CHECK_ARG(x && wpk && dw_w && fft_w && out && B > 0 && E > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0);
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     FDN_CHECK_ARG(16ull * E * H * W < 0x80000000ull && 4ull * C * H * W < 0x80000000ull);   // 32-bit byte offsets per image
     FusedArgs a;
-    a.x = x; a.xbs = xbs; a.stats = stats; a.wpk = wpk; a.bpk = bpk; a.dww = dw_w; a.fftw = fft_w; a.out = out;
+    a.x = x; a.xbs = xbs; a.stats = stats; a.wpk = wpk; a.dww = dw_w; a.fftw = fft_w; a.out = out;
     a.E = E; a.H = H; a.W = W;
     a.tiles_x = cdiv(W, FT_W);
     a.tiles_per_img = a.tiles_x * (H / FT_H);
     a.nchunks = (E + FEG - 1) / FEG;
     const long total = (long)B * a.tiles_per_img;
     FDN_CHECK_ARG(total < 0x7fffffffL);
+    const int cus = fdn_device_cus();
+    if (cus <= 0) return FDN_ERR_LAUNCH;
+    a.stagger_lo = cus;                 // two workgroups per CU: the second one of each CU's first pair
+    a.stagger_hi = 2 * cus;
     const dim3 grid((unsigned)total), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define FDN_FUSED_CASE(CC)                                                                                        \

@@ -29,7 +29,7 @@ class Conv1x1Desc(ctypes.Structure):
         ("stats", c_fp), ("gamma", c_fp), ("beta", c_fp), ("xb", c_fp), ("xbbs", ctypes.c_long),
         ("act", ctypes.c_int), ("epi", ctypes.c_int),
         ("res", c_fp), ("rbs", ctypes.c_long), ("mul", c_fp), ("add", c_fp), ("mbs", ctypes.c_long),
-        ("vec4", ctypes.c_int), ("stats_out", c_fp),
+        ("vec4", ctypes.c_int), ("stats_out", c_fp), ("x_bf16", ctypes.c_int), ("out_bf16", ctypes.c_int),
     ]
 
 
@@ -37,7 +37,7 @@ class FdnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5          # include/fdn_hip.h: bumped on any signature change
+ABI_VERSION = 6          # include/fdn_hip.h: bumped on any signature change
 
 
 def lib_path():

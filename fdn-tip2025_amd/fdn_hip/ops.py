@@ -9,15 +9,17 @@ import os
 import torch
 
 from . import (ACT_NONE, EPI_MULADD, EPI_NONE, EPI_RES, PRO_LN, PRO_LN3_GATE, PRO_LN_MULADD, PRO_NONE,
-               Conv1x1Desc, FdnHipError, check, lib, stream)
+               Conv1x1Desc, FdnHipError, check, lib, storage_dtype, stream)
+
+BF16 = torch.bfloat16
 
 
-def _planes(t, what):
+def _planes(t, what, bf16_ok=False):
     """(device pointer, batch stride in elements) of an NCHW tensor whose C,H,W dims are dense."""
     if not t.is_cuda:
         raise FdnHipError(f"{what} must live on a ROCm device (got {t.device}); the FDN path has no CPU fallback")
-    if t.dtype != torch.float32:
-        raise FdnHipError(f"{what} must be float32 (got {t.dtype})")
+    if t.dtype != torch.float32 and not (bf16_ok and t.dtype == BF16):
+        raise FdnHipError(f"{what} must be float32{' or bfloat16 storage' if bf16_ok else ''} (got {t.dtype})")
     assert t.dim() == 4, what
     _, C, H, W = t.shape
     st = t.stride()
@@ -26,12 +28,19 @@ def _planes(t, what):
     return ctypes.c_void_p(t.data_ptr()), (st[0] if t.shape[0] > 1 else C * H * W)
 
 
-def _flat(t, what):
+def _flat(t, what, bf16_ok=False):
     if t is None:
         return None
-    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+    if not t.is_cuda or not (t.dtype == torch.float32 or (bf16_ok and t.dtype == BF16)) or not t.is_contiguous():
         raise FdnHipError(f"{what} must be a contiguous float32 ROCm tensor")
     return ctypes.c_void_p(t.data_ptr())
+
+
+def block_storage(C, P):
+    """Storage dtype of the block-internal activations of an FDSA / FDFFN block of input width C and P pixels:
+    bf16 in bf16-storage mode for the blocks whose kernels carry the bf16 load / store forms (levels 1-2: C <= 64,
+    pixel pairs), fp32 otherwise (level 3 is bound by the matrix cores, not by bytes)."""
+    return BF16 if storage_dtype() == "bf16" and C <= 64 and P % 4 == 0 else torch.float32
 
 
 class WeightCache:
@@ -83,7 +92,7 @@ def fold_ln(w, bias, gamma, beta):
 
 
 def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None, ln_muladd=None, res=None,
-            muladd=None, want_stats=False, cache=None):
+            muladd=None, want_stats=False, cache=None, out_dtype=torch.float32):
     """1x1 conv with fused prologue/epilogue (fdn_conv1x1).
 
     want_stats: also produce the channel-LayerNorm statistics of the output in the epilogue and attach
@@ -93,6 +102,8 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
     ln=(stats, gamma, beta) | ln3_gate=(stats, gamma[3E], beta[3E], vv) | ln_muladd=(stats, gamma, beta, x1)
     res: residual added after act | muladd=(mul, add).
     cache=(WeightCache, name): where the LayerNorm-folded operands of `ln` are kept (else they are rebuilt per call).
+    out_dtype=torch.bfloat16 stores the result as bf16 (FDFFN project_in); a bf16 `xs` is read as bf16 storage
+    (FDFFN project_out).  The library refuses forms it has no bf16 kernel for.
     """
     if torch.is_tensor(xs):
         xs = [xs]
@@ -102,14 +113,16 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
     K = sum(x.shape[1] for x in xs)
     assert w.numel() == N * K, (w.shape, K)
     if out is None:
-        out = torch.empty((B, N, H, W), device=xs[0].device, dtype=torch.float32)
+        out = torch.empty((B, N, H, W), device=xs[0].device, dtype=out_dtype)
     d = Conv1x1Desc()
     for i, x in enumerate(xs):
-        d.x[i], d.xbs[i] = _planes(x, f"x[{i}]")
+        d.x[i], d.xbs[i] = _planes(x, f"x[{i}]", bf16_ok=(i == 0 and len(xs) == 1))
         d.kseg[i] = x.shape[1]
+    d.x_bf16 = int(xs[0].dtype == BF16)
+    d.out_bf16 = int(out.dtype == BF16)
     d.w = _flat(w, "w")
     d.bias = _flat(bias, "bias")
-    d.out, d.obs = _planes(out, "out")
+    d.out, d.obs = _planes(out, "out", bf16_ok=True)
     d.B, d.K, d.N, d.P = B, K, N, P
     d.pro, d.ln_group = PRO_NONE, K
     if ln is not None:
@@ -189,22 +202,21 @@ def fdsa_pack(w, gamma, beta):
     E4, C = w.shape[0], w.shape[1]
     E = E4 // 4
     nch = (E + 7) // 8
-    wpk = torch.empty((nch, C // 2, 64), device=w.device, dtype=torch.float32)
-    bpk = torch.empty((nch, 32), device=w.device, dtype=torch.float32)
+    wpk = torch.empty((nch, C // 2 + 1, 64), device=w.device, dtype=torch.float32)
     check(lib().fdn_fdsa_pack(_flat(w.reshape(E4, C), "w"), _flat(gamma, "gamma"), _flat(beta, "beta"), _flat(wpk, "wpk"),
-                              _flat(bpk, "bpk"), C, E, stream()), "fdn_fdsa_pack")
-    return wpk, bpk
+                              C, E, stream()), "fdn_fdsa_pack")
+    return wpk
 
 
-def fdsa_fused(x, stats, wpk, bpk, dw_w, fft_w):
+def fdsa_fused(x, stats, wpk, dw_w, fft_w, out_dtype=torch.float32):
     """LayerNorm + to_hidden + fdsa_core in one launch (fdn_fdsa_fused): x [B,C,H,W] -> (out1|out2|out3|v_value) [B,4E,H,W]."""
     B, C, H, W = x.shape
     E = fft_w.shape[0]
     assert C in FDSA_FUSED_C, C
-    out = torch.empty((B, 4 * E, H, W), device=x.device, dtype=torch.float32)
+    out = torch.empty((B, 4 * E, H, W), device=x.device, dtype=out_dtype)
     ptr, xbs = _planes(x, "x")
-    check(lib().fdn_fdsa_fused(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), _flat(wpk, "wpk"), _flat(bpk, "bpk"),
-                               _flat(dw_w, "dw_w"), _flat(fft_w, "fft_w"), _flat(out, "out"), B, C, E, H, W, stream()),
+    check(lib().fdn_fdsa_fused(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), _flat(wpk, "wpk"), _flat(dw_w, "dw_w"),
+                               _flat(fft_w, "fft_w"), _flat(out, "out", True), B, C, E, H, W, int(out_dtype == BF16), stream()),
           "fdn_fdsa_fused")
     return out
 
@@ -217,9 +229,9 @@ def fdsa_out(o, w, gamma3, beta3, res=None, want_stats=False):
         return None
     out = torch.empty((B, N, H, W), device=o.device, dtype=torch.float32)
     stats = torch.empty((B, 1, 2, P), device=o.device, dtype=torch.float32) if want_stats else None
-    rc = lib().fdn_fdsa_out(_flat(o, "o"), _flat(w, "w"), _flat(gamma3, "gamma3"), _flat(beta3, "beta3"), _flat(res, "res"),
-                            _flat(out, "out"), _flat(stats, "stats_out"), B, E, N, P, stream())
-    if rc == 4:          # FDN_ERR_UNSUPPORTED
+    rc = lib().fdn_fdsa_out(_flat(o, "o", True), _flat(w, "w"), _flat(gamma3, "gamma3"), _flat(beta3, "beta3"), _flat(res, "res"),
+                            _flat(out, "out"), _flat(stats, "stats_out"), B, E, N, P, int(o.dtype == BF16), stream())
+    if rc == 4 and o.dtype != BF16:          # FDN_ERR_UNSUPPORTED: the caller takes the statistics + GEMM route (fp32 only)
         return None
     check(rc, "fdn_fdsa_out")
     if want_stats:
@@ -227,11 +239,13 @@ def fdsa_out(o, w, gamma3, beta3, res=None, want_stats=False):
     return out
 
 
-def fdffn_mid(x, w0, w2, ffta, fftp):
+def fdffn_mid(x, w0, w2, ffta, fftp, out_dtype=None):
+    """x may be bf16 storage; out_dtype defaults to x's."""
     B, Hd, H, W = x.shape
-    out = torch.empty_like(x)
-    check(lib().fdn_fdffn_mid(_flat(x, "x"), _flat(w0, "w0"), _flat(w2, "w2"), _flat(ffta, "ffta"), _flat(fftp, "fftp"),
-                              _flat(out, "out"), B, Hd, H, W, stream()), "fdn_fdffn_mid")
+    out = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    check(lib().fdn_fdffn_mid(_flat(x, "x", True), _flat(w0, "w0"), _flat(w2, "w2"), _flat(ffta, "ffta"), _flat(fftp, "fftp"),
+                              _flat(out, "out", True), B, Hd, H, W, int(x.dtype == BF16), int(out.dtype == BF16), stream()),
+          "fdn_fdffn_mid")
     return out
 
 
@@ -242,9 +256,9 @@ def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None):
     # measured on MI355X (tools/bench_kernels.py tail, B=8 720p): with the sliding-window gate kernel the two-launch
     # form (gate kernel + MFMA GEMM) beats the fused launch almost everywhere (level 1: 2.24 vs 3.17 ms, level 3:
     # 0.91 vs 1.11 ms); the fused kernel wins only for the 64 -> 64 FCAFFN tail of level 2 (0.72 vs 0.87 ms)
-    fused = (C == 64 and N == 64) if mode is None else mode == "fused"
+    fused = (C == 64 and N == 64 and y.dtype == torch.float32) if mode is None else mode == "fused"
     if not fused:
-        g = dwconv_gate(y, dw_w)
+        g = dwconv_gate(y, dw_w)                 # (bf16 storage in -> bf16 storage out -> the project_out conv reads bf16)
         return conv1x1(g, w, res=res, want_stats=want_stats)
     out = torch.empty((B, N, H, W), device=y.device, dtype=torch.float32)
     stats = torch.empty((B, 1, 2, H * W), device=y.device, dtype=torch.float32) if want_stats else None
@@ -255,10 +269,12 @@ def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None):
     return out
 
 
-def dwconv_gate(x, w):
+def dwconv_gate(x, w, out_dtype=None):
+    """x may be bf16 storage; out_dtype defaults to x's."""
     B, C, H, W = x.shape
-    out = torch.empty_like(x)
-    check(lib().fdn_dwconv_gate(_flat(x, "x"), _flat(w, "w"), _flat(out, "out"), B, C, H, W, stream()), "fdn_dwconv_gate")
+    out = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    check(lib().fdn_dwconv_gate(_flat(x, "x", True), _flat(w, "w"), _flat(out, "out", True), B, C, H, W, int(x.dtype == BF16),
+                                int(out.dtype == BF16), stream()), "fdn_dwconv_gate")
     return out
 
 

@@ -14,6 +14,12 @@
  *     (a hipStream_t; NULL = the default stream).  The one exception is the immutable FFT twiddle
  *     table of a size, built on first use of that size (fdn_fft_prepare does it explicitly);
  *   - return value: FDN_OK or an FDN_ERR_* code; the Python layer maps non-zero to RuntimeError.
+ *
+ * Storage formats.  Everything is fp32 (the reference's arithmetic, BASELINE.json configs[1]) unless an entry point has an
+ * `*_bf16` flag and the caller sets it: that one tensor is then STORED as bf16 (2 bytes per element, same [B][C][H][W]
+ * layout, widened to fp32 on load, rounded to nearest-even on store).  Only block-internal activations of FDSA / FDFFN have
+ * such a flag (out1|out2|out3|v_value; the FDFFN hidden tensors); all arithmetic, FFTs, LayerNorm statistics, the residual
+ * stream and every other tensor stay fp32 (BASELINE.json configs[2], "bf16 storage").
  */
 #ifndef FDN_HIP_H
 #define FDN_HIP_H
@@ -72,6 +78,8 @@ typedef struct fdn_conv1x1_desc {
     int vec4; /* set by the library */
     float* stats_out; /* optional [B][1][2][P]: (mean, rstd) over the N output channels of `out` (needs N <= 160):
                          the LayerNorm statistics the NEXT block needs, produced in this epilogue */
+    int x_bf16;       /* x[0] is stored as bf16 (xbs in elements): FDFFN project_out forms only, else FDN_ERR_UNSUPPORTED */
+    int out_bf16;     /* out is stored as bf16 (obs in elements): FDFFN project_in forms only (K <= 64, N >= 2K) */
 } fdn_conv1x1_desc;
 int fdn_conv1x1(const fdn_conv1x1_desc* d, fdn_stream_t stream);
 
@@ -95,34 +103,35 @@ int fdn_fdsa_core(const float* hidden, const float* dw_w, const float* fft_w, fl
  * to_hidden (1x1 conv C -> 4E on the matrix cores, evaluated on the 1-pixel halo of each 8x32 tile) and everything
  * fdn_fdsa_core does; the 4E-channel hidden tensor never reaches HBM.
  * fdn_fdsa_pack: to_hidden weight w [4E][C] (+ optional LayerNorm gamma, beta [C], folded in: w*diag(gamma), w@beta)
- *   -> wpk [ceil(E/8)][C/2][64] (MFMA A operands per chunk of 8 channels, k-step, lane), bpk [ceil(E/8)][32].
+ *   -> wpk [ceil(E/8)][C/2+1][64] (MFMA A operands per chunk of 8 channels, k-step, lane; the last k-step is the bias row).
  * fdn_fdsa_fused: x [B][C][H][W] (batch stride xbs), stats [B][2][P] = (mean, rstd) of x over C or NULL (no
  *   LayerNorm; then pack without gamma / beta), dw_w [4E][9], fft_w [E][8][5]
  *   -> out [B][4E][H][W] = (out1|out2|out3|v_value_dw), exactly fdn_fdsa_core's output.
- * C in {24, 32, 48, 64} (the two upper levels of FDN and FDN_lolv1), else FDN_ERR_UNSUPPORTED. */
-int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, float* bpk, int C, int E,
-                  fdn_stream_t stream);
-int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* bpk, const float* dw_w,
-                   const float* fft_w, float* out, int B, int C, int E, int H, int W, fdn_stream_t stream);
+ * C in {24, 32, 48, 64} (the two upper levels of FDN and FDN_lolv1), else FDN_ERR_UNSUPPORTED.
+ * out_bf16: store `out` as bf16 (bf16-storage mode, see "Storage formats" above). */
+int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, fdn_stream_t stream);
+int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
+                   void* out, int B, int C, int E, int H, int W, int out_bf16, fdn_stream_t stream);
 
 /* FDSA tail in one launch (FDN_arch.py:633-639 and the residual add of :671): norm1/2/3 over the E channels
  * of out1|out2|out3, times v_value, project_out (3E -> N) + res, and (optionally) the channel LayerNorm
  * statistics of the result.  o [B][4E][P] as written by fdn_fdsa_core; w [N][3E]; gamma3,beta3 [3E];
  * stats_out [B][2][P] or NULL.  Register-resident form, E <= 76 and N <= 64: other sizes return
- * FDN_ERR_UNSUPPORTED (use fdn_chan_stats + fdn_conv1x1 with FDN_PRO_LN3_GATE). */
-int fdn_fdsa_out(const float* o, const float* w, const float* gamma3, const float* beta3, const float* res, float* out,
-                 float* stats_out, int B, int E, int N, int P, fdn_stream_t stream);
+ * FDN_ERR_UNSUPPORTED (use fdn_chan_stats + fdn_conv1x1 with FDN_PRO_LN3_GATE).  o_bf16: `o` is stored as bf16. */
+int fdn_fdsa_out(const void* o, const float* w, const float* gamma3, const float* beta3, const float* res, float* out,
+                 float* stats_out, int B, int E, int N, int P, int o_bf16, fdn_stream_t stream);
 
 /* FDFFN middle: spatial branch dw3x3 -> GELU -> dw3x3 (FDN_arch.py:435-441,457) plus frequency
  * branch 8x8 rfft2 -> replace_denormals -> amplitude*ffta, phase-fftp -> irfft2 (:458-469), summed
- * (:470).  x [B][Hd][H][W], w0,w2 [Hd][9], ffta,fftp [Hd][8][5] -> out [B][Hd][H][W]. */
-int fdn_fdffn_mid(const float* x, const float* w0, const float* w2, const float* ffta, const float* fftp, float* out,
-                  int B, int Hd, int H, int W, fdn_stream_t stream);
+ * (:470).  x [B][Hd][H][W], w0,w2 [Hd][9], ffta,fftp [Hd][8][5] -> out [B][Hd][H][W].  x_bf16 / out_bf16: storage of x / out. */
+int fdn_fdffn_mid(const void* x, const float* w0, const float* w2, const float* ffta, const float* fftp, void* out,
+                  int B, int Hd, int H, int W, int x_bf16, int out_bf16, fdn_stream_t stream);
 
 /* Gated depthwise conv: Conv2d(C, 2C, 3, groups=C) then gelu(x1)*x2 (FDN_arch.py:472-473,:426-427).
  * x [B][C][H][W], w [2C][9] -> out [B][C][H][W];
- * out[j] = gelu(dw(x[j/2], w[j])) * dw(x[(C+j)/2], w[C+j]). */
-int fdn_dwconv_gate(const float* x, const float* w, float* out, int B, int C, int H, int W, fdn_stream_t stream);
+ * out[j] = gelu(dw(x[j/2], w[j])) * dw(x[(C+j)/2], w[C+j]).  x_bf16 / out_bf16: storage of x / out. */
+int fdn_dwconv_gate(const void* x, const float* w, void* out, int B, int C, int H, int W, int x_bf16, int out_bf16,
+                    fdn_stream_t stream);
 
 /* FDFFN / FCAFFN tail in one launch: gated depthwise conv (FDN_arch.py:472-473, :426-427) + project_out
  * (:474, :428) + residual (:673, :675) + LayerNorm statistics of the result.  y [B][C][H][W]; dw_w [2C][9];

@@ -45,8 +45,8 @@ def _fdsa_taps(sd, x, fused):
     from fdn_hip import ops
     w, dw, fw = dev(sd["to_hidden.weight"].reshape(-1, x.shape[1])), dev(sd["to_hidden_dw.weight"]), dev(sd["fft"])
     if fused:
-        wpk, bpk = ops.fdsa_pack(w, None, None)
-        o = ops.fdsa_fused(dev(x), None, wpk, bpk, dw, fw)
+        wpk = ops.fdsa_pack(w, None, None)
+        o = ops.fdsa_fused(dev(x), None, wpk, dw, fw)
     else:
         o = ops.fdsa_core(ops.conv1x1(dev(x), w), dw, fw)
     E = fw.shape[0]

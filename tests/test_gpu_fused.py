@@ -44,13 +44,13 @@ def test_fdsa_fused_equals_unfused(A, C, H, W, B, ln):
     if ln:
         st = ops.chan_stats(x)
         hidden = ops.conv1x1(x, w, ln=(st, g, b_))
-        wpk, bpk = ops.fdsa_pack(w, g, b_)
+        wpk = ops.fdsa_pack(w, g, b_)
     else:
         st = None
         hidden = ops.conv1x1(x, w)
-        wpk, bpk = ops.fdsa_pack(w, None, None)
+        wpk = ops.fdsa_pack(w, None, None)
     ref = ops.fdsa_core(hidden, dw, fw)
-    got = ops.fdsa_fused(x, st, wpk, bpk, dw, fw)
+    got = ops.fdsa_fused(x, st, wpk, dw, fw)
     torch.cuda.synchronize()
     assert torch.isfinite(got).all()
     err = (got - ref).abs().max().item() / ref.abs().max().item()
@@ -68,8 +68,8 @@ def test_fdsa_fused_batch_slices_and_edges(A):
     g, b_ = dev(torch.ones(C)), dev(_rnd(C, seed=13))          # a bias: the out-of-image halo must still read as 0
     dw, fw = dev(_rnd(4 * E, 1, 3, 3, seed=14) / 3), dev(torch.ones(E, 1, 1, 8, 5))
     st = ops.chan_stats(x.contiguous())
-    wpk, bpk = ops.fdsa_pack(w, g, b_)
-    got = ops.fdsa_fused(x, st, wpk, bpk, dw, fw)
+    wpk = ops.fdsa_pack(w, g, b_)
+    got = ops.fdsa_fused(x, st, wpk, dw, fw)
     ref = ops.fdsa_core(ops.conv1x1(x.contiguous(), w, ln=(st, g, b_)), dw, fw)
     assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-6
 

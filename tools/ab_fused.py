@@ -30,8 +30,8 @@ for lvl in (1, 2):
     r = lambda *s: torch.randn(*s, device=dev)
     x = r(B, C, H, W); st = ops.chan_stats(x); g, b_ = r(C), r(C)
     wh = r(4 * E, C) / C ** .5; dw, fw = r(4 * E, 1, 3, 3), r(E, 1, 1, 8, 5)
-    wpk, bpk = ops.fdsa_pack(wh, g, b_)
-    print(f"L{lvl} fdsa_fused {timeit(lambda: ops.fdsa_fused(x, st, wpk, bpk, dw, fw)):.3f} ms", flush=True)
+    wpk = ops.fdsa_pack(wh, g, b_)
+    print(f"L{lvl} fdsa_fused {timeit(lambda: ops.fdsa_fused(x, st, wpk, dw, fw)):.3f} ms", flush=True)
     if hasattr(ops, "fdffn_fused"):
         wi = r(Hd, C) / C ** .5
         w0, w2, fa, fp = r(Hd, 1, 3, 3), r(Hd, 1, 3, 3), r(Hd, 1, 1, 8, 5), r(Hd, 1, 1, 8, 5)

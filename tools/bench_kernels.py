@@ -37,8 +37,8 @@ for lvl in (1, 2, 3):
     hidden = ops.conv1x1(x, wh, ln=(st, g, b_))
     dw, fw = r(4 * E, 1, 3, 3), r(E, 1, 1, 8, 5)
     if want("fdsa_fused") and C in ops.FDSA_FUSED_C:
-        wpk, bpk = ops.fdsa_pack(wh, g, b_)
-        rep(f"L{lvl} fdsa_fused (LN+to_hidden+core) C={C} E={E}", timeit(lambda: ops.fdsa_fused(x, st, wpk, bpk, dw, fw)), B * P * (C + 4 * E), 2. * B * P * C * 4 * E)
+        wpk = ops.fdsa_pack(wh, g, b_)
+        rep(f"L{lvl} fdsa_fused (LN+to_hidden+core) C={C} E={E}", timeit(lambda: ops.fdsa_fused(x, st, wpk, dw, fw)), B * P * (C + 4 * E), 2. * B * P * C * 4 * E)
     if want("fdsa_core"):
         rep(f"L{lvl} fdsa_core E={E}", timeit(lambda: ops.fdsa_core(hidden, dw, fw)), B * P * 8 * E)
     o = ops.fdsa_core(hidden, dw, fw)
