@@ -547,7 +547,11 @@ __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restri
 //     strip and parks the 32 x 32 result in the LDS hidden tile (zero outside the image = the conv's zero padding);
 //   * then thread = (channel of the chunk, patch, row): stencil -> row rfft -> LDS spectra -> column phase
 //     (160 threads) -> inverse rows -> 32-byte stores, the code of fdsa_core_kernel.
-// HBM traffic: C planes in (+26 % halo, mostly L2 hits: each XCD owns a contiguous run of tiles), 4E planes out.
+// HBM traffic: C planes in (+33 % halo, mostly L2 hits: each XCD owns a contiguous run of tiles), 4E planes out.
+// Measured (MI355X, level 1, B = 8): 3.0-3.2 ms against 1.1-1.4 + 2.2-2.5 ms for fdn_conv1x1 + fdn_fdsa_core.  PMC view
+// (profiles/r02_fdsa_fused_pmc.txt): 6.0k vector instructions per wave at 4 issue cycles each + 234 fp32 MFMAs at 64 cycles are 62 % of
+// a wave's life; a second workgroup per CU buys nothing (one per CU: 3.02 ms, two: 3.06 ms) and staggering the pair changes
+// nothing either - the fp32 MFMA and the vector ALU do not overlap on a SIMD, their cycles add.
 // ------------------------------------------------------------------------------------------
 constexpr int FT_H = 8, FT_W = 32;
 constexpr int FHW = FT_W + 2, FHH = FT_H + 2;      // halo tile 10 x 34
@@ -567,7 +571,6 @@ struct FusedArgs {
     const float* fftw;
     float* out;
     int E, H, W, tiles_x, tiles_per_img, nchunks;
-    int stagger_lo, stagger_hi;        // workgroups [lo, hi) start half a chunk late (see the kernel)
 };
 
 template <int C, bool LN, bool OBF>          // OBF: the (out1|out2|out3|v_value) planes are stored as bf16
@@ -662,14 +665,6 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     aw_fetch(0);
     stage_fetch(0);
     stage_store();                      // (visible behind the first barrier of the loop)
-    // Two workgroups share a CU and would run their phases in lockstep (matrix cores busy while the vector ALUs idle, then
-    // the reverse): the second wave of workgroups the dispatcher hands out starts half a chunk late, and every later
-    // workgroup inherits the offset of the slot it takes over.
-    if ((int)blockIdx.x >= a.stagger_lo && (int)blockIdx.x < a.stagger_hi) {
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(64);
-    }
-
     for (int ch = 0; ch < a.nchunks; ++ch) {
         const int e0 = ch * FEG;
         const int e = e0 + el;
@@ -878,10 +873,6 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
     a.nchunks = (E + FEG - 1) / FEG;
     const long total = (long)B * a.tiles_per_img;
     FDN_CHECK_ARG(total < 0x7fffffffL);
-    const int cus = fdn_device_cus();
-    if (cus <= 0) return FDN_ERR_LAUNCH;
-    a.stagger_lo = cus;                 // two workgroups per CU: the second one of each CU's first pair
-    a.stagger_hi = 2 * cus;
     const dim3 grid((unsigned)total), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define FDN_FUSED_CASE(CC)                                                                                        \
