@@ -79,6 +79,16 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) {  // a * conj(b)
 }
 __device__ __forceinline__ float cabs2(float2 a) { return sqrtf(a.x * a.x + a.y * a.y); }
 
+// Workgroup -> work item for tiled kernels.  The dispatcher deals workgroups round-robin over the 8 XCDs (blocks b and b + 8
+// share one, MI355X_MICROARCH.md), so with the natural order horizontally adjacent tiles of a plane land on different XCDs and
+// the 128-byte lines both touch (a halo row of 64 + 2 floats spans 4 lines, 2 of them shared) are fetched from the fabric twice:
+// the stencil kernels read 2.1-2.2x their input that way (profiles/r02_a_traffic_groups.json).  xcd_contiguous maps block L of T
+// to item S so that every XCD walks a contiguous run of items in dispatch order; callers decode S with the tile index fastest.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned L, unsigned T) {
+    const unsigned xcd = L & 7u, idx = L >> 3, per = T >> 3, rem = T & 7u;
+    return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 STORAGE of block-internal activations (BASELINE.json configs[2]).  bf16 is only a
 // memory format here: a value is widened to fp32 when loaded (exact) and rounded to nearest-even when stored

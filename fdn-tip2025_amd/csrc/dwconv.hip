@@ -117,16 +117,18 @@ __device__ __forceinline__ void dw_gate_rows(const float* ta, const float* tb0, 
 
 template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as bf16 (fp32 math either way)
 __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      float* __restrict__ out, int C, int H, int W, int tiles_x) {
+                                                      float* __restrict__ out, int C, int H, int W, int tiles_x, int ntiles) {
     constexpr unsigned IES = st_bytes<IBF>(), OES = st_bytes<OBF>();
+    const int npairs = (C + 1) / 2;
+    const unsigned item = xcd_contiguous(blockIdx.x, gridDim.x);           // (b, output pair, tile), tile fastest
     __shared__ float ta[(TH + 2) * LS + 4];
     __shared__ float tb[2][(TH + 2) * LS + 4];
-    const int m = blockIdx.y, b = blockIdx.z;
+    const int tile = item % ntiles, m = (item / ntiles) % npairs, b = item / (ntiles * npairs);
     const int j0 = 2 * m, j1 = 2 * m + 1;
     const bool has1 = j1 < C;
     const int cb0 = (C + j0) >> 1, cb1 = (C + j1) >> 1;     // grouped conv: output o reads input o/2
     const bool same = cb1 == cb0 || !has1;
-    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const unsigned hw4 = (unsigned)H * W * IES, hwo = (unsigned)H * W * OES;
     const rsrc_t rin = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + (long)b * C * H * W * IES), (unsigned)C * hw4);
     const rsrc_t rout = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(out) + (long)b * C * H * W * OES), (unsigned)C * hwo);
@@ -220,10 +222,12 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void img_maps_kernel(const float* __restrict__ img, const float* __restrict__ w1m,
                                                        const float* __restrict__ w3m, const float* __restrict__ w1a,
                                                        const float* __restrict__ w3a, float* __restrict__ mul,
-                                                       float* __restrict__ add, int C, int H, int W, int tiles_x) {
+                                                       float* __restrict__ add, int C, int H, int W, int tiles_x, int ntiles) {
     __shared__ float t[3][(TH + 2) * LS + 1];
-    const int b = blockIdx.z;
-    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int ncg = (C + 7) / 8;
+    const unsigned item = xcd_contiguous(blockIdx.x, gridDim.x);           // (b, channel chunk, tile), tile fastest
+    const int tile = item % ntiles, cgi = (item / ntiles) % ncg, b = item / (ntiles * ncg);
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const unsigned hw4 = (unsigned)H * W * 4u;
     const rsrc_t rin = mk_rsrc(img + (long)b * 3 * H * W, 3u * hw4);
     {
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) void img_maps_kernel(const float* __restrict__
     const unsigned row4 = (unsigned)W * 4u;
     const rsrc_t rmul = mk_rsrc(mul + (long)b * C * H * W, (unsigned)C * hw4);
     const rsrc_t radd = mk_rsrc(add + (long)b * C * H * W, (unsigned)C * hw4);
-    const int c0 = blockIdx.y * 8, nc = min(8, C - c0);               // channel chunk of this workgroup
+    const int c0 = cgi * 8, nc = min(8, C - c0);                      // channel chunk of this workgroup
     float win[3][3][3];                                                 // [window row][plane][dx]
     auto load_row = [&](int hr, int k) {
 #pragma unroll
@@ -310,9 +314,9 @@ extern "C" int fdn_dwconv_gate(const void* x_, const float* w, void* out_, int B
     FDN_CHECK_ARG(4ull * C * H * W < 0x80000000ull);          // one image's C planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     const bool v4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    const dim3 grid(tx * ty, (C + 1) / 2, B);
+    const dim3 grid((unsigned)(tx * ty) * ((C + 1) / 2) * B);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define FDN_GATE(V, I, O) hipLaunchKernelGGL((dw_gate_kernel<V, I, O>), grid, dim3(256), 0, s, x, w, out, C, H, W, tx)
+#define FDN_GATE(V, I, O) hipLaunchKernelGGL((dw_gate_kernel<V, I, O>), grid, dim3(256), 0, s, x, w, out, C, H, W, tx, tx * ty)
     if (v4) {
         if (x_bf16 && out_bf16) FDN_GATE(true, true, true);
         else if (x_bf16) FDN_GATE(true, true, false);
@@ -334,7 +338,7 @@ extern "C" int fdn_img_mod_maps(const float* img, const float* w1_mul, const flo
     FDN_CHECK_ARG(img && w1_mul && w3_mul && w1_add && w3_add && mul && add && B > 0 && C > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(4ull * C * H * W < 0x80000000ull);          // one image's C planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
-    hipLaunchKernelGGL(img_maps_kernel, dim3(tx * ty, cdiv(C, 8), B), dim3(256), 0, static_cast<hipStream_t>(stream), img,
-                       w1_mul, w3_mul, w1_add, w3_add, mul, add, C, H, W, tx);
+    hipLaunchKernelGGL(img_maps_kernel, dim3((unsigned)(tx * ty) * cdiv(C, 8) * B), dim3(256), 0, static_cast<hipStream_t>(stream), img,
+                       w1_mul, w3_mul, w1_add, w3_add, mul, add, C, H, W, tx, tx * ty);
     return fdn_launch_status();
 }

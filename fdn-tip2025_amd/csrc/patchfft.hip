@@ -224,13 +224,14 @@ __device__ __forceinline__ void stencil_row8(const float* t, int row, int col0, 
 template <bool V4>
 __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restrict__ hidden, const float* __restrict__ dww,
                                                            const float* __restrict__ fftw, float* __restrict__ out, int E,
-                                                           int H, int W, int tiles_x) {
+                                                           int H, int W, int tiles_x, int ntiles) {
     __shared__ float halo[2][(TH + 2) * HS + 4];
     __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
 
     const int tid = threadIdx.x;
-    const int e = blockIdx.y, b = blockIdx.z;
-    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const unsigned item = xcd_contiguous(blockIdx.x, gridDim.x);           // (b, e, tile), tile fastest
+    const int tile = item % ntiles, e = (item / ntiles) % E, b = item / (ntiles * E);
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const unsigned hw4 = (unsigned)H * W * 4u;                  // bytes per plane; 4E planes per image < 4 GB (checked by the host)
     const long base = (long)b * 4 * E * H * W;
     const rsrc_t rin = mk_rsrc(hidden + base, 4u * E * hw4);
@@ -359,15 +360,17 @@ template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as 
 __global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                            const float* __restrict__ w2, const float* __restrict__ ffta,
                                                            const float* __restrict__ fftp, float* __restrict__ out, int Hd,
-                                                           int H, int W, int tiles_x) {
+                                                           int H, int W, int tiles_x, int ntiles) {
     __shared__ float tin[(TH + 4) * LS2 + 4];       // halo 2 (+ spare cells)
     __shared__ float mid[(TH + 2) * LSM];           // gelu(dw0(x)) on halo 1
     __shared__ __attribute__((aligned(16))) float2 S[NP * PS];
     __shared__ float2 filt[40];                     // ffta * e^{-i fftp} per (ky, kx)
 
     const int tid = threadIdx.x;
-    const int cbase = blockIdx.y * CPB, b = blockIdx.z;
-    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int ngroups = (Hd + CPB - 1) / CPB;
+    const unsigned item = xcd_contiguous(blockIdx.x, gridDim.x);           // (b, channel group, tile), tile fastest
+    const int tile = item % ntiles, cbase = ((item / ntiles) % ngroups) * CPB, b = item / (ntiles * ngroups);
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     constexpr unsigned IES = st_bytes<IBF>(), OES = st_bytes<OBF>();
     const unsigned hw4 = (unsigned)H * W * IES;                 // bytes per input plane; Hd planes per image < 4 GB (checked by the host)
     const unsigned hwo = (unsigned)H * W * OES;
@@ -581,11 +584,7 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     __shared__ float fgs[FEG * 40];                                   // fft gains of the chunk's channels: [channel][ky][kx]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
-    int t_ = blockIdx.x;
-    {   // blocks b and b + 8 share an XCD (round-robin dispatch): give every XCD a contiguous run of tiles
-        const int n = gridDim.x;
-        if ((n & 7) == 0) t_ = (t_ & 7) * (n >> 3) + (t_ >> 3);
-    }
+    const int t_ = (int)xcd_contiguous(blockIdx.x, gridDim.x);            // every XCD walks a contiguous run of tiles
     const int b = t_ / a.tiles_per_img, ti = t_ - b * a.tiles_per_img;
     const int ty0 = (ti / a.tiles_x) * FT_H, tx0 = (ti % a.tiles_x) * FT_W;
     const int E = a.E, H = a.H, W = a.W;
@@ -821,11 +820,11 @@ extern "C" int fdn_fdsa_core(const float* hidden, const float* dw_w, const float
     FDN_CHECK_ARG(16ull * E * H * W < 0x80000000ull);          // one image's 4E planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(hidden) & 15) == 0)
-        hipLaunchKernelGGL(fdsa_core_kernel<true>, dim3(tx * ty, E, B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
-                           fft_w, out, E, H, W, tx);
+        hipLaunchKernelGGL(fdsa_core_kernel<true>, dim3((unsigned)(tx * ty) * E * B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
+                           fft_w, out, E, H, W, tx, tx * ty);
     else
-        hipLaunchKernelGGL(fdsa_core_kernel<false>, dim3(tx * ty, E, B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
-                           fft_w, out, E, H, W, tx);
+        hipLaunchKernelGGL(fdsa_core_kernel<false>, dim3((unsigned)(tx * ty) * E * B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
+                           fft_w, out, E, H, W, tx, tx * ty);
     return fdn_launch_status();
 }
 
@@ -840,12 +839,13 @@ extern "C" int fdn_fdffn_mid(const void* x_, const float* w0, const float* w2, c
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     // (the 16-byte-lane halo fetch, V4 = true, measured slower here - 1.95 vs 1.80 ms at level 1: this kernel is bound by
     // VALU issue, and the float4 stash costs four LDS writes per load)
-    const dim3 grid(tx * ty, (Hd + CPB - 1) / CPB, B);
+    const dim3 grid((unsigned)(tx * ty) * ((Hd + CPB - 1) / CPB) * B);
+    const int nt = tx * ty;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (x_bf16 && out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx);
-    else if (x_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx);
-    else if (out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, false, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx);
-    else hipLaunchKernelGGL((fdffn_mid_kernel<false, false, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx);
+    if (x_bf16 && out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
+    else if (x_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
+    else if (out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, false, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
+    else hipLaunchKernelGGL((fdffn_mid_kernel<false, false, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
     return fdn_launch_status();
 }
 
