@@ -842,6 +842,7 @@ extern "C" int fdn_fdffn_mid(const void* x_, const float* w0, const float* w2, c
     const dim3 grid((unsigned)(tx * ty) * ((Hd + CPB - 1) / CPB) * B);
     const int nt = tx * ty;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // (a two-channels-per-thread packed-fp32 form measured slower - occupancy - see tools/experiments/fdffn_mid_pair_kernel.hip.inc)
     if (x_bf16 && out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
     else if (x_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
     else if (out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, false, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
