@@ -114,8 +114,9 @@ def describe_call(name, a):
         key = f"fdn_dwconv_gate[C={C},{H}x{W}{',bf16' if ib + ob < 8 else ''}]"
     elif name == "fdn_ffn_tail":
         B, C, N, H, W = (_iv(v) for v in a[6:11])
-        f, b = 2.0 * B * H * W * C * N, 4.0 * B * H * W * (C + 2 * N)
-        key = f"fdn_ffn_tail[{C}->{N},{H}x{W}]"
+        ib = 2.0 if _iv(a[11]) else 4.0
+        f, b = 2.0 * B * H * W * C * N, B * H * W * (ib * C + 4.0 * 2 * N)
+        key = f"fdn_ffn_tail[{C}->{N},{H}x{W},form{_iv(a[12])}{',ibf16' if ib == 2.0 else ''}]"
     elif name == "fdn_rfft_rows":
         rows, W = _iv(a[2]), _iv(a[3])
         b = 4.0 * rows * (W + 2 * (W // 2 + 1))

@@ -210,6 +210,245 @@ __global__ __launch_bounds__(NT) void ffn_tail_kernel(FtArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sliding-window form (round 2).  Same fusion, different decomposition: the workgroup walks the hidden channels in PAIRS
+// (j0, j1 = 2m, 2m + 1: exactly one k-step of v_mfma_f32_32x32x2_f32) for a fixed 2R x 64 pixel tile.
+//   * a wave owns R rows x 32 columns; lane = (column n, k parity kh) evaluates channel 2m + kh at its column for the R rows
+//     with a sliding 3 x 3 window per source plane (3 LDS reads per row and plane, as fdn_dwconv_gate), GELU and the gate
+//     product - and that value IS the MFMA B operand of its row (lane = pixel, lane half = k), no transpose, no LDS hop;
+//   * the R x MT accumulators (16 registers each) stay in registers over the whole channel loop; the epilogue adds the
+//     residual, stores 128-byte row segments and emits the next LayerNorm's statistics;
+//   * the source planes of pair m + 1 (2, or 3 when C is odd) travel global -> registers (16-byte lanes) during pair m and are
+//     parked in the other half of a double-buffered LDS tile: one barrier per pair.
+// Per pixel and pair: 2 x (9 + 9) FMAs + 2 GELUs on the vector ALU and MT MFMAs - 0.9 ms of SIMD time for the level-1 FDFFN
+// tail against 0.9 ms of HBM time for its 150 planes; the gate tensor (C planes written + read: 5 GB at level 1) is gone.
+// ------------------------------------------------------------------------------------------------
+constexpr int SW_TC = 64;                 // tile columns (two 32-column wave strips)
+constexpr int SW_LS = 68;                 // LDS row stride of a halo plane (66 used)
+constexpr unsigned SW_OOB = 0x80000000u;
+
+template <int MT, int R, bool IBF>
+__global__ __launch_bounds__(256, (R * MT <= 4) ? 2 : 1) void ffn_tail_sw_kernel(FtArgs a) {
+    constexpr int HRW = 2 * R + 2;                       // halo rows of the tile
+    constexpr int PLN = HRW * SW_LS + 4;                 // floats per plane (+ spare cells)
+    constexpr int NV4 = HRW * 16;                        // float4 of the 64 interior columns
+    constexpr int V4T = (NV4 + 255) / 256;               // per thread
+    constexpr unsigned IES = st_bytes<IBF>();
+    __shared__ __attribute__((aligned(16))) float planes[2][3][PLN];
+    __shared__ __attribute__((aligned(16))) float dwl[2][2][20];          // [buffer][k parity][wA(9), pad, wB(9), pad]
+
+    const int C = a.C, N = a.N, H = a.H, W = a.W;
+    const unsigned P = (unsigned)H * W, hwi = P * IES, hw4 = P * 4u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int item = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = item / a.tiles_per_img, t_ = item - b * a.tiles_per_img;
+    const int ty0 = (t_ / a.tiles_x) * (2 * R), tx0 = (t_ % a.tiles_x) * SW_TC;
+    const rsrc_t rin = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.y) + (long)b * C * P * IES), (unsigned)C * hwi);
+    const bool codd = (C & 1) != 0;
+    const int npairs = (C + 1) / 2;
+
+    // ---- loaders: 16-byte lanes for the interior, dwords for the two edge columns (W % 4 == 0: a float4 is inside or outside) ----
+    unsigned g4[V4T], ge;
+    int s4[V4T], se;
+#pragma unroll
+    for (int i = 0; i < V4T; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 4, c4 = idx & 15;
+        const int y = ty0 - 1 + r, xx = tx0 + 4 * c4;
+        const bool ok = idx < NV4 && y >= 0 && y < H && xx < W;
+        g4[i] = ok ? (unsigned)(y * W + xx) * IES : SW_OOB;
+        s4[i] = idx < NV4 ? r * SW_LS + 1 + 4 * c4 : HRW * SW_LS;
+    }
+    {
+        const int er = tid >> 1, ec = (tid & 1) ? SW_TC + 1 : 0;
+        const int ey = ty0 - 1 + er, ex = tx0 - 1 + ec;
+        const bool eok = tid < 2 * HRW && ey >= 0 && ey < H && ex >= 0 && ex < W;
+        ge = eok ? (unsigned)(ey * W + ex) * IES : SW_OOB;
+        se = tid < 2 * HRW ? er * SW_LS + ec : HRW * SW_LS;
+    }
+    // two register stages: the planes of pair m + 2 are requested while pair m is evaluated (one pair of arithmetic is ~0.4 us,
+    // an HBM round trip under load several times that), parked in LDS a pair later
+    struct Stage { float q4[3][V4T][4], qe[3], pdw, aw[MT]; };
+    Stage stg[2];
+    auto fetch = [&](int m, Stage& st) {
+        float (&q4)[3][V4T][4] = st.q4;
+        float (&qe)[3] = st.qe;
+        float& pdw = st.pdw;
+        float (&aw_n)[MT] = st.aw;
+        pdw = 0.f;
+        const int j0 = 2 * m, j1 = (2 * m + 1 < C) ? 2 * m + 1 : 2 * m;
+        const int pa = m, pb0 = (C + j0) >> 1, pb1 = (C + j1) >> 1;            // grouped conv: output o reads input o / 2
+#pragma unroll
+        for (int i = 0; i < V4T; ++i) {
+            st_load4<IBF>(q4[0][i], rin, g4[i], (unsigned)pa * hwi);
+            st_load4<IBF>(q4[1][i], rin, g4[i], (unsigned)pb0 * hwi);
+            if (codd) st_load4<IBF>(q4[2][i], rin, g4[i], (unsigned)pb1 * hwi);
+        }
+        qe[0] = st_load1<IBF>(rin, ge, (unsigned)pa * hwi);
+        qe[1] = st_load1<IBF>(rin, ge, (unsigned)pb0 * hwi);
+        if (codd) qe[2] = st_load1<IBF>(rin, ge, (unsigned)pb1 * hwi);
+        if (tid < 40) {                                      // depthwise taps of channels 2m, 2m + 1: [parity][wA | wB]
+            const int par = tid / 20, i = tid - par * 20, j = 2 * m + par;
+            const int tap = i < 10 ? i : i - 10;
+            pdw = (j < C && tap < 9) ? a.wdw[(long)((i < 10 ? 0 : C) + j) * 9 + tap] : 0.f;
+        }
+        const int j = 2 * m + kh;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) aw_n[t] = (j < C && t * 32 + ln < N) ? a.w[(long)(t * 32 + ln) * C + j] : 0.f;
+    };
+    auto stash = [&](int buf, const Stage& st) {
+        const float (&q4)[3][V4T][4] = st.q4;
+        const float (&qe)[3] = st.qe;
+        const float pdw = st.pdw;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            if (pl == 2 && !codd) break;
+#pragma unroll
+            for (int i = 0; i < V4T; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) planes[buf][pl][s4[i] + e] = q4[pl][i][e];
+            planes[buf][pl][se] = qe[pl];
+        }
+        if (tid < 40) dwl[buf][tid / 20][tid % 20] = pdw;
+    };
+
+    f32x16 acc[R][MT];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][t][q] = 0.f;
+
+    fetch(0, stg[0]);
+    if (npairs > 1) fetch(1, stg[1]);
+    float aw[MT], aw_next[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        aw[t] = stg[0].aw[t];
+        aw_next[t] = stg[1].aw[t];
+    }
+    stash(0, stg[0]);
+    __syncthreads();
+
+    const int r0 = wy * R, col = wx * 32 + ln;
+    auto pair_step = [&](int m, Stage& mine, const Stage& nxt) {
+        // `mine` held pair m (already parked in LDS, its registers are free): refill it with pair m + 2; `nxt` holds pair m + 1
+        const int buf = m & 1;
+        const bool more = m + 1 < npairs;
+        if (m + 2 < npairs) fetch(m + 2, mine);
+        // taps of this lane's channel
+        float wa[9], wb[9];
+        {
+            const float* dp = dwl[buf][kh];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                wa[i] = dp[i];
+                wb[i] = dp[10 + i];
+            }
+        }
+        const float* pA = planes[buf][0] + r0 * SW_LS + col;
+        const float* pB = planes[buf][(codd && kh) ? 2 : 1] + r0 * SW_LS + col;
+        // window rows live in a ring of four: row i + 3 is requested while row i (rows i .. i + 2) is evaluated, so the LDS
+        // latency hides behind a row's arithmetic
+        float wA_[4][3], wB_[4][3];
+        auto load_row = [&](int hr, int k) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                wA_[k][dx] = pA[hr * SW_LS + dx];
+                wB_[k][dx] = pB[hr * SW_LS + dx];
+            }
+        };
+        load_row(0, 0);
+        load_row(1, 1);
+        load_row(2, 2);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if (i + 3 < R + 2) load_row(i + 3, (i + 3) & 3);
+            float sA = 0.f, sB = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int k = (i + dy) & 3;
+                    sA = fmaf(wa[dy * 3 + dx], wA_[k][dx], sA);
+                    sB = fmaf(wb[dy * 3 + dx], wB_[k][dx], sB);
+                }
+            const float val = gelu_fast(sA) * sB;                                   // gelu(x1) * x2, FDN_arch.py:473 / :427
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val, acc[i][t], 0, 0, 0);
+        }
+        if (more) {
+            stash(buf ^ 1, nxt);                             // (that half was last read two pairs ago, behind the previous barrier)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) aw[t] = nxt.aw[t];
+        }
+        __syncthreads();
+    };
+    for (int m = 0; m < npairs; m += 2) {
+        pair_step(m, stg[0], stg[1]);
+        if (m + 1 < npairs) pair_step(m + 1, stg[1], stg[0]);
+    }
+
+    // ---- epilogue: residual, store, next LayerNorm's statistics ----------------------------------------------------------
+    const int gx = tx0 + col;
+    const unsigned nb4 = (unsigned)N * hw4;
+    const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
+    const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gy = ty0 + r0 + i;
+        const bool ok = gy < H && gx < W;
+        const unsigned pix = ok ? (unsigned)(gy * W + gx) : 0u;
+        const unsigned vo = ok ? (4u * kh * P + pix) * 4u : SW_OOB;
+        float rres[MT][16];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rres[t][q] = bload(rr, vo, (unsigned)(t * 32 + (q & 3) + 8 * (q >> 2)) * hw4);     // 0 without a residual
+        float sm = 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int nrow = t * 32 + (q & 3) + 8 * (q >> 2);
+                float v = acc[i][t][q] + rres[t][q];
+                bstore(v, ro, vo, (unsigned)nrow * hw4);                              // rows >= N fall outside the descriptor
+                v = (nrow + 4 * kh < N) ? v : 0.f;
+                acc[i][t][q] = v;
+                sm += v;
+            }
+        if (a.stats_out) {
+            sm += __shfl_xor(sm, 32);
+            const float mean = sm / (float)N;
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float dl = acc[i][t][q] - mean;
+                    sq += (t * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh < N) ? dl * dl : 0.f;
+                }
+            sq += __shfl_xor(sq, 32);
+            if (kh == 0 && ok) {
+                float* sp = a.stats_out + (long)b * 2 * P;
+                sp[pix] = mean;
+                sp[P + pix] = 1.0f / sqrtf(sq / (float)N + 1e-5f);
+            }
+        }
+    }
+}
+
+template <int MT, int R, bool IBF>
+int launch_sw(FtArgs a, hipStream_t s) {
+    a.tiles_x = cdiv(a.W, SW_TC);
+    a.tiles_per_img = a.tiles_x * cdiv(a.H, 2 * R);
+    a.total_tiles = a.B * a.tiles_per_img;
+    hipLaunchKernelGGL((ffn_tail_sw_kernel<MT, R, IBF>), dim3((unsigned)a.total_tiles), dim3(256), 0, s, a);
+    return fdn_launch_status();
+}
+
 template <int MT>
 int launch(FtArgs a, hipStream_t s) {
     const int g_cus = fdn_device_cus();
@@ -225,8 +464,9 @@ int launch(FtArgs a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int fdn_ffn_tail(const float* y, const float* dw_w, const float* w, const float* res, float* out, float* stats_out,
-                            int B, int C, int N, int H, int W, fdn_stream_t stream) {
+extern "C" int fdn_ffn_tail(const void* y_, const float* dw_w, const float* w, const float* res, float* out, float* stats_out,
+                            int B, int C, int N, int H, int W, int y_bf16, int form, fdn_stream_t stream) {
+    const float* y = static_cast<const float*>(y_);
     FDN_CHECK_ARG(y && dw_w && w && out && B > 0 && C > 0 && N > 0 && H > 0 && W > 0);
     if (N > 128) return FDN_ERR_UNSUPPORTED;
     if ((unsigned long long)(C + 2) * 4ull * H * W >= 0x80000000ull || (unsigned long long)(N + 40) * 4ull * H * W >= 0x80000000ull)
@@ -237,6 +477,12 @@ extern "C" int fdn_ffn_tail(const float* y, const float* dw_w, const float* w, c
     a.tiles_x = a.tiles_per_img = a.total_tiles = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int mt = (N + 31) / 32;
+    if (form == 1) {                                             // sliding-window form: N <= 64, 16-byte input lanes
+        if (W % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0 || mt > 2) return FDN_ERR_UNSUPPORTED;
+        if (mt == 1) return y_bf16 ? launch_sw<1, 4, true>(a, s) : launch_sw<1, 4, false>(a, s);
+        return y_bf16 ? launch_sw<2, 2, true>(a, s) : launch_sw<2, 2, false>(a, s);
+    }
+    if (y_bf16) return FDN_ERR_UNSUPPORTED;
     if (mt == 1) return launch<1>(a, s);
     if (mt == 2) return launch<2>(a, s);
     if (mt == 3) return launch<3>(a, s);

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.environ.get("FDN_HIP_LIB") or os.path.join(_HERE, "libfdn_hip.so")   # override: A/B builds of the same ABI
+_LIB_PATH = os.path.join(_HERE, "libfdn_hip.so")      # (measurement tools that A/B another build of the same ABI set this before lib())
 _lib = None
 
 ACT_NONE, ACT_LEAKY, ACT_RELU, ACT_SIGMOID, ACT_GELU = 0, 1, 2, 3, 4
@@ -53,13 +53,22 @@ def lib():
                 f"{_LIB_PATH} not found: build it with fdn-tip2025_amd/build.sh (hipcc --offload-arch=gfx950). "
                 "The FDN path has no CPU fallback.")
         _lib = ctypes.CDLL(_LIB_PATH)
-        _lib.fdn_error_string.restype = ctypes.c_char_p
-        _lib.fdn_abi_version.restype = ctypes.c_int
+        _declare(_lib)
         if _lib.fdn_abi_version() != ABI_VERSION:
             v = _lib.fdn_abi_version()
             _lib = None
             raise ImportError(f"{_LIB_PATH} has ABI version {v}, this binding needs {ABI_VERSION}: rebuild with build.sh")
     return _lib
+
+
+def _declare(l):
+    """argtypes / restype of every entry point (a wrong argument count or kind raises here instead of corrupting the call)."""
+    from ._abi import PROTOTYPES
+    kinds = {"P": ctypes.c_void_p, "I": ctypes.c_int, "L": ctypes.c_long, "F": ctypes.c_float, "DESC": ctypes.POINTER(Conv1x1Desc)}
+    for name, (ret, sig) in PROTOTYPES.items():
+        f = getattr(l, name)                       # AttributeError: the library lacks a symbol the header declares
+        f.restype = ctypes.c_char_p if ret == "S" else ctypes.c_int
+        f.argtypes = [kinds[k] for k in sig]
 
 
 def check(code, what):

@@ -249,21 +249,30 @@ def fdffn_mid(x, w0, w2, ffta, fftp, out_dtype=None):
     return out
 
 
+FFN_TAIL_MODE = None          # None = per-shape choice below; "sw" | "fused" | "split" forces one (A/B runs, tests)
+
+
 def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None):
-    """gate + project_out + residual (+ next LayerNorm statistics) in one launch (fdn_ffn_tail)."""
+    """gate + project_out + residual (+ next LayerNorm statistics).
+      "sw"    one launch, sliding-window kernel (fdn_ffn_tail form 1): N <= 64, W % 4 == 0, fp32 or bf16-storage y;
+      "fused" one launch, the chunked kernel of round 1 (fdn_ffn_tail form 0), fp32 y;
+      "split" fdn_dwconv_gate then the project_out GEMM (the gated tensor makes a round trip through HBM)."""
     B, C, H, W = y.shape
     N = w.shape[0]
-    # measured on MI355X (tools/bench_kernels.py tail, B=8 720p): with the sliding-window gate kernel the two-launch
-    # form (gate kernel + MFMA GEMM) beats the fused launch almost everywhere (level 1: 2.24 vs 3.17 ms, level 3:
-    # 0.91 vs 1.11 ms); the fused kernel wins only for the 64 -> 64 FCAFFN tail of level 2 (0.72 vs 0.87 ms)
-    fused = (C == 64 and N == 64 and y.dtype == torch.float32) if mode is None else mode == "fused"
-    if not fused:
+    mode = mode or FFN_TAIL_MODE
+    if mode is None:
+        # measured on MI355X (tools/bench_kernels.py tail, B = 8 720p): one launch wins for the 32-wide outputs (level 1: FDFFN 86 -> 32
+        # 1.60 vs 1.94 ms, FCAFFN 32 -> 32 0.75 vs 0.97 ms) and for the 64 -> 64 FCAFFN tail of level 2 (0.56 vs 0.76 ms); the deep
+        # 172 -> 64 FDFFN tail of level 2 (1.24 vs 1.06 ms) and everything at level 3 stay on gate + GEMM
+        mode = "sw" if (W % 4 == 0 and (N <= 32 or (N <= 64 and C <= 64))) else "split"
+    if mode == "split":
         g = dwconv_gate(y, dw_w)                 # (bf16 storage in -> bf16 storage out -> the project_out conv reads bf16)
         return conv1x1(g, w, res=res, want_stats=want_stats)
     out = torch.empty((B, N, H, W), device=y.device, dtype=torch.float32)
     stats = torch.empty((B, 1, 2, H * W), device=y.device, dtype=torch.float32) if want_stats else None
-    check(lib().fdn_ffn_tail(_flat(y, "y"), _flat(dw_w, "dw_w"), _flat(w, "w"), _flat(res, "res"), _flat(out, "out"),
-                             _flat(stats, "stats_out"), B, C, N, H, W, stream()), "fdn_ffn_tail")
+    check(lib().fdn_ffn_tail(_flat(y, "y", True), _flat(dw_w, "dw_w"), _flat(w, "w"), _flat(res, "res"), _flat(out, "out"),
+                             _flat(stats, "stats_out"), B, C, N, H, W, int(y.dtype == BF16), 1 if mode == "sw" else 0, stream()),
+          "fdn_ffn_tail")
     if want_stats:
         out._fdn_stats = stats
     return out

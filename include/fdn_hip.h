@@ -134,10 +134,12 @@ int fdn_dwconv_gate(const void* x, const float* w, void* out, int B, int C, int 
                     fdn_stream_t stream);
 
 /* FDFFN / FCAFFN tail in one launch: gated depthwise conv (FDN_arch.py:472-473, :426-427) + project_out
- * (:474, :428) + residual (:673, :675) + LayerNorm statistics of the result.  y [B][C][H][W]; dw_w [2C][9];
- * w [N][C]; res/out [B][N][H][W]; stats_out [B][2][H*W] or NULL.  N <= 128. */
-int fdn_ffn_tail(const float* y, const float* dw_w, const float* w, const float* res, float* out, float* stats_out, int B,
-                 int C, int N, int H, int W, fdn_stream_t stream);
+ * (:474, :428) + residual (:673, :675) + LayerNorm statistics of the result; the gated tensor never reaches HBM.
+ * y [B][C][H][W] (y_bf16: stored as bf16); dw_w [2C][9]; w [N][C]; res/out [B][N][H][W]; stats_out [B][2][H*W] or NULL.
+ * form 1: sliding-window kernel (channel pairs walked per 16x64 / 8x64 pixel tile, accumulators resident; N <= 64, W % 4 == 0);
+ * form 0: chunked kernel of round 1 (N <= 128, fp32 y).  Unsupported combinations return FDN_ERR_UNSUPPORTED. */
+int fdn_ffn_tail(const void* y, const float* dw_w, const float* w, const float* res, float* out, float* stats_out, int B,
+                 int C, int N, int H, int W, int y_bf16, int form, fdn_stream_t stream);
 
 /* Plain depthwise 3x3 (zero pad 1), optional activation.  x,out [B][C][H][W], w [C][9]. */
 int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, int C, int H, int W, int act, fdn_stream_t stream);

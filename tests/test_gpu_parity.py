@@ -276,26 +276,40 @@ def test_conv1x1_variants(A, K, N, H, W, pro):
     assert rel_rms(st[:, 0], mu) < tol and rel_rms(st[:, 1], 1 / torch.sqrt(var + 1e-5)) < tol
 
 
-@pytest.mark.parametrize("C,N,H,W", [(86, 32, 24, 40), (345, 128, 16, 24), (64, 64, 46, 40), (43, 16, 8, 35)])
+@pytest.mark.parametrize("C,N,H,W", [(86, 32, 24, 40), (345, 128, 16, 24), (64, 64, 46, 40), (43, 16, 8, 35), (172, 64, 40, 72),
+                                     (129, 48, 16, 136), (32, 32, 736, 1280)])
 def test_ffn_tail_fused_equals_reference(A, C, N, H, W):
-    """fdn_ffn_tail (gate + project_out + residual + statistics in one launch) against fp64, odd widths too."""
+    """fdn_ffn_tail (gate + project_out + residual + statistics in one launch, both kernel forms) against fp64: odd widths,
+    odd channel counts (the gate branch of a pair then reads two different planes), partial 64-column tiles, bf16-storage input."""
     import ctypes
     import fdn_hip
     from fdn_hip import ops
-    B = 2
+    B = 2 if H * W < 100000 else 1
     y, wd, w, res = _rnd(B, C, H, W, seed=1), _rnd(2 * C, 1, 3, 3, seed=2) * 0.3, _rnd(N, C, seed=3) / C ** 0.5, _rnd(B, N, H, W, seed=4)
     F = torch.nn.functional
     a, g = F.conv2d(y.double(), wd.double(), padding=1, groups=C).chunk(2, 1)
     ref = F.conv2d(F.gelu(a) * g, w.double().view(N, C, 1, 1)) + res.double()
-    out = torch.empty(B, N, H, W, device="cuda:0")
-    st = torch.empty(B, 1, 2, H * W, device="cuda:0")
     yd, wdd, wdv, rd = dev(y), dev(wd), dev(w), dev(res)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    rc = fdn_hip.lib().fdn_ffn_tail(p(yd), p(wdd), p(wdv), p(rd), p(out), p(st), B, C, N, H, W, fdn_hip.stream())
-    assert rc == 0
-    assert rel_rms(out.cpu(), ref) < 3e-6
-    assert rel_rms(st.cpu().view(B, 2, H, W)[:, 0], ref.mean(1)) < 1e-5
-    assert rel_rms(ops.ffn_tail(yd, wdd, wdv, res=rd).cpu(), ref) < 3e-6         # whichever path the dispatcher picks
+    forms = [0] + ([1] if N <= 64 and W % 4 == 0 else [])
+    for form in forms:
+        out = torch.empty(B, N, H, W, device="cuda:0")
+        st = torch.empty(B, 1, 2, H * W, device="cuda:0")
+        rc = fdn_hip.lib().fdn_ffn_tail(p(yd), p(wdd), p(wdv), p(rd), p(out), p(st), B, C, N, H, W, 0, form, fdn_hip.stream())
+        assert rc == 0, (form, rc)
+        assert rel_rms(out.cpu(), ref) < 3e-6, form
+        assert rel_rms(st.cpu().view(B, 2, H, W)[:, 0], ref.mean(1)) < 1e-5, form
+        assert rel_rms(st.cpu().view(B, 2, H, W)[:, 1], 1 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5)) < 1e-5, form
+    for mode in ("split", None):
+        assert rel_rms(ops.ffn_tail(yd, wdd, wdv, res=rd, mode=mode).cpu(), ref) < 3e-6, mode
+    if 1 in forms:                                             # bf16-storage input: reads exactly the stored values
+        yb = yd.to(torch.bfloat16)
+        got = ops.ffn_tail(yb, wdd, wdv, res=rd, want_stats=True, mode="sw")
+        want = ops.ffn_tail(yb.float(), wdd, wdv, res=rd, want_stats=True, mode="sw")
+        assert torch.equal(got, want) and torch.equal(got._fdn_stats, want._fdn_stats)
+    if N > 64 or W % 4:
+        with pytest.raises(fdn_hip.FdnHipError):
+            ops.ffn_tail(yd, wdd, wdv, res=rd, mode="sw")
 
 
 @pytest.mark.parametrize("Cin,Cout,H,W,stride", [(64, 32, 24, 40, 1), (3, 32, 16, 35, 1), (12, 12, 9, 21, 1), (32, 3, 16, 24, 1),

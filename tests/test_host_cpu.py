@@ -30,6 +30,22 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.fdn_error_string(1).decode().startswith("invalid argument")
 
 
+def test_ctypes_prototypes_match_header(lib):
+    """fdn_hip/_abi.py (argtypes of every entry point) is exactly what include/fdn_hip.h declares, and the loader applied it."""
+    import importlib.util
+    import ctypes as C
+    from fdn_hip._abi import PROTOTYPES
+    spec = importlib.util.spec_from_file_location("gen_abi_table", os.path.join(ROOT, "tools", "gen_abi_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert PROTOTYPES == gen.parse_header(os.path.join(ROOT, "include", "fdn_hip.h"))
+    assert lib.fdn_fdsa_fused.argtypes is not None and len(lib.fdn_fdsa_fused.argtypes) == len(PROTOTYPES["fdn_fdsa_fused"][1])
+    with pytest.raises(C.ArgumentError):
+        lib.fdn_fdsa_core(None, None, None, None, 1.5, 38, 32, 32, None)            # a float where an int belongs
+    with pytest.raises(TypeError):
+        lib.fdn_fdsa_core(None, None, None, None, 1, 38, 32, 32)          # one argument short
+
+
 def test_argument_validation_without_gpu(lib):
     # NULL pointers / bad sizes are rejected before any launch
     assert lib.fdn_fdsa_core(None, None, None, None, 1, 38, 32, 32, None) == 1

@@ -89,5 +89,7 @@ for lvl in (1, 2, 3):
         y = torch.randn(B, cc, H, W, device=dev); wg = torch.randn(2 * cc, 1, 3, 3, device=dev); wo = torch.randn(nn, cc, device=dev) / cc ** .5
         res = torch.randn(B, nn, H, W, device=dev)
         rep(f"L{lvl} {tag} tail FUSED {cc}->{nn}", timeit(lambda: ops.ffn_tail(y, wg, wo, res=res, want_stats=True, mode="fused")), B * P * (cc + 2 * nn))
-        rep(f"L{lvl} {tag} tail gate+gemm {cc}->{nn}", timeit(lambda: ops.conv1x1(ops.dwconv_gate(y, wg), wo, res=res, want_stats=True)), B * P * (cc + 2 * nn))
+        if nn <= 64:
+            rep(f"L{lvl} {tag} tail SLIDING {cc}->{nn}", timeit(lambda: ops.ffn_tail(y, wg, wo, res=res, want_stats=True, mode="sw")), B * P * (cc + 2 * nn), 2. * B * P * cc * nn)
+        rep(f"L{lvl} {tag} tail gate+gemm {cc}->{nn}", timeit(lambda: ops.ffn_tail(y, wg, wo, res=res, want_stats=True, mode="split")), B * P * (cc + 2 * nn))
         del y, res

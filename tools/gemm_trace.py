@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
 import torch
 import fdn_hip
+if os.environ.get('FDN_HIP_LIB'): fdn_hip._LIB_PATH = os.path.abspath(os.environ['FDN_HIP_LIB'])   # A/B build of the same ABI
 from fdn_hip import Conv1x1Desc
 dev = torch.device("cuda:0")
 B, K, N, H, W = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 345, int(sys.argv[2]) if len(sys.argv) > 2 else 128, 184, 320
