@@ -1,7 +1,8 @@
-"""Validation metrics on the GPU: the reference's defaults, basicsr/metrics/psnr_ssim.py `calculate_psnr` (:8-73) and the
-`ssim3d=True` path of `calculate_ssim` (:163-197, :215-290), for (C,H,W) or (1,C,H,W) float32 ROCm tensors in RGB/any
-channel order (both metrics are symmetric in the channels except for the 3-D window, which sees them in the given order,
-as the reference does).  `test_y_channel` is not covered (off in the LOL-Blur options).  No CPU fallback."""
+"""Validation metrics on the GPU: the reference's basicsr/metrics/psnr_ssim.py `calculate_psnr` (:8-73) and `calculate_ssim`
+(:243-328) with all their branches - the default 3-D Gaussian SSIM (`ssim3d=True`, :163-197), the 2-D one (`ssim3d=False`, `_ssim`
+:84-116) and the Y-channel variants (`test_y_channel=True`: `to_y_channel` + `_ssim_cly` :199-240) - for (C,H,W) or (1,C,H,W) float32
+ROCm tensors.  With `test_y_channel` the channels must be in B, G, R order and the range [0, 255], as the reference's callers pass
+them (`tensor2img(..., rgb2bgr=True)`).  No CPU fallback."""
 import ctypes
 import math
 
@@ -25,16 +26,31 @@ def _prep(img1, img2, crop_border):
     return out
 
 
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def _sse_max(a, b):
     acc = torch.zeros(2, dtype=torch.float64, device=a.device)
-    check(lib().fdn_sse_max(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), ctypes.c_long(a.numel()),
-                            ctypes.c_void_p(acc.data_ptr()), stream()), "fdn_sse_max")
+    check(lib().fdn_sse_max(_ptr(a), _ptr(b), ctypes.c_long(a.numel()), _ptr(acc), stream()), "fdn_sse_max")
     sse, mx = acc.tolist()
     return sse, mx
 
 
-def calculate_psnr(img1, img2, crop_border=0):
+def to_y_channel(img_bgr):
+    """(3,H,W) B,G,R in [0, 255] -> (1,H,W) Y in [16, 235] (metric_util.py:34-47)."""
+    if img_bgr.shape[0] != 3:
+        raise FdnHipError("to_y_channel needs a 3-channel (B, G, R) image")
+    _, H, W = img_bgr.shape
+    out = torch.empty((1, H, W), dtype=torch.float32, device=img_bgr.device)
+    check(lib().fdn_y_channel(_ptr(img_bgr), _ptr(out), H, W, stream()), "fdn_y_channel")
+    return out
+
+
+def calculate_psnr(img1, img2, crop_border=0, test_y_channel=False):
     a, b = _prep(img1, img2, crop_border)
+    if test_y_channel:                                                                                 # :55-57
+        a, b = to_y_channel(a), to_y_channel(b)
     sse, mx = _sse_max(a, b)
     mse = sse / a.numel()
     if mse == 0:
@@ -43,13 +59,26 @@ def calculate_psnr(img1, img2, crop_border=0):
     return 20.0 * math.log10(max_value / math.sqrt(mse))
 
 
-def calculate_ssim(img1, img2, crop_border=0):
+def _ssim2d(a, b, max_value, replicate_no_crop):
+    C, H, W = a.shape
+    ws = torch.empty(5 * a.numel(), dtype=torch.float64, device=a.device)
+    acc = torch.zeros(1, dtype=torch.float64, device=a.device)
+    check(lib().fdn_ssim2d(_ptr(a), _ptr(b), C, H, W, ctypes.c_float(max_value), int(replicate_no_crop), _ptr(ws), _ptr(acc), stream()),
+          "fdn_ssim2d")
+    count = C * H * W if replicate_no_crop else C * (H - 10) * (W - 10)
+    return float(acc.item()) / count
+
+
+def calculate_ssim(img1, img2, crop_border=0, test_y_channel=False, ssim3d=True):
     a, b = _prep(img1, img2, crop_border)
+    if test_y_channel:                                                                                 # :275-278: Y plane, _ssim_cly
+        return _ssim2d(to_y_channel(a), to_y_channel(b), 255.0, True)
     C, H, W = a.shape
     mx = float(a.max().item())
-    max_value = 1.0 if mx <= 1 else 255.0                                                              # :268
+    max_value = 1.0 if mx <= 1 else 255.0                                                              # :286
+    if not ssim3d:
+        return _ssim2d(a, b, max_value, False)                                                         # _ssim, :84-116
     ws = torch.empty(10 * a.numel(), dtype=torch.float32, device=a.device)
     acc = torch.zeros(1, dtype=torch.float64, device=a.device)
-    check(lib().fdn_ssim3d(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), C, H, W, ctypes.c_float(max_value),
-                           ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(acc.data_ptr()), stream()), "fdn_ssim3d")
+    check(lib().fdn_ssim3d(_ptr(a), _ptr(b), C, H, W, ctypes.c_float(max_value), _ptr(ws), _ptr(acc), stream()), "fdn_ssim3d")
     return float(acc.item()) / a.numel()

@@ -236,6 +236,16 @@ int fdn_tiles_merge(const float* tiles, float* out, const int* ij, int T, int C,
 int fdn_sse_max(const float* a, const float* b, long n, double* out2, fdn_stream_t stream);
 int fdn_ssim3d(const float* a, const float* b, int C, int H, int W, float max_value, float* ws, double* out_sum,
                fdn_stream_t stream);
+/* The other branches of the same two functions.
+ * fdn_y_channel: test_y_channel=True (psnr_ssim.py:55-57, :275-277 -> metric_util.py:34-47 -> matlab_functions.py:207-238, y_only):
+ *   img_bgr [3][H][W] in B, G, R order, range [0, 255] -> out [H][W] = Y of ITU-R BT.601 in [16, 235], with the reference's mix of
+ *   float32 / float64 steps.  PSNR on Y = fdn_sse_max of two Y planes.
+ * fdn_ssim2d: the 2-D Gaussian SSIM in float64, per channel: replicate_no_crop = 0 is _ssim (:84-116; cv2.filter2D's default
+ *   reflect-101 border, map restricted to [5:-5, 5:-5]; mean = sum / (C (H-10) (W-10))), 1 is _ssim_cly (:199-240; BORDER_REPLICATE,
+ *   whole map; mean = sum / (C H W), used on the Y plane with max_value 255).  ws = 5*C*H*W doubles (caller zeroes out_sum). */
+int fdn_y_channel(const float* img_bgr, float* out, int H, int W, fdn_stream_t stream);
+int fdn_ssim2d(const float* a, const float* b, int C, int H, int W, float max_value, int replicate_no_crop, double* ws,
+               double* out_sum, fdn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -487,6 +487,69 @@ def ssim_3d(img1, img2, crop_border=0):
     return float(ssim_map.mean())
 
 
+def to_y_channel(img_chw_bgr):
+    """basicsr/metrics/metric_util.py:34-47 + utils/matlab_functions.py:207-238 (bgr2ycbcr, y_only) for a (3,H,W) BGR tensor in
+    [0, 255]: float32 image / 255, float64 dot with (24.966, 128.553, 65.481) + 16, / 255 back to float32, * 255 in float32."""
+    x = (img_chw_bgr.to(torch.float32) / 255.0).to(torch.float64)
+    y = x[0] * 24.966 + x[1] * 128.553 + x[2] * 65.481 + 16.0
+    return ((y / 255.0).to(torch.float32) * 255.0)[None]                       # (1,H,W), float32, range [16, 235]
+
+
+def _filter2d(img, window, border):
+    """cv2.filter2D(img, -1, window, borderType) on a float64 (H,W) plane (OpenCV is not vendored by the reference: correlation,
+    anchor at the centre; default border BORDER_REFLECT_101 = torch 'reflect', BORDER_REPLICATE = 'replicate')."""
+    r = window.shape[0] // 2
+    t = F.pad(img[None, None], (r, r, r, r), mode=border)
+    return F.conv2d(t, window[None, None])[0, 0]
+
+
+def _ssim_planes(a, b, C1, C2, border, crop):
+    k = gaussian_kernel_11()
+    window = torch.outer(k, k)
+    f = lambda t: _filter2d(t, window, border)
+    cut = (lambda t: t[5:-5, 5:-5]) if crop else (lambda t: t)
+    mu1, mu2 = cut(f(a)), cut(f(b))
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 ** 2, mu2 ** 2, mu1 * mu2
+    s1, s2, s12 = cut(f(a * a)) - mu1_sq, cut(f(b * b)) - mu2_sq, cut(f(a * b)) - mu1_mu2
+    return ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+
+
+def ssim_2d(img1, img2, crop_border=0):
+    """calculate_ssim(ssim3d=False) -> _ssim, psnr_ssim.py:84-116: per channel an 11x11 Gaussian filter in float64 (cv2.filter2D,
+    default reflect-101 border), the valid region [5:-5, 5:-5] only, mean over (H-10, W-10, C)."""
+    a, b = img1.to(torch.float64), img2.to(torch.float64)
+    if crop_border:
+        a, b = a[..., crop_border:-crop_border, crop_border:-crop_border], b[..., crop_border:-crop_border, crop_border:-crop_border]
+    max_value = 1 if a.max().item() <= 1 else 255
+    C1, C2 = (0.01 * max_value) ** 2, (0.03 * max_value) ** 2
+    maps = [_ssim_planes(a[c], b[c], C1, C2, "reflect", True) for c in range(a.shape[0])]
+    return float(torch.stack(maps).mean())
+
+
+def ssim_y(img1_bgr, img2_bgr, crop_border=0):
+    """calculate_ssim(test_y_channel=True) -> to_y_channel + _ssim_cly, psnr_ssim.py:199-240, :275-278: the Y plane, 11x11 Gaussian
+    with BORDER_REPLICATE, no valid-region crop, constants for a 255 range."""
+    a, b = img1_bgr.to(torch.float64), img2_bgr.to(torch.float64)
+    if crop_border:
+        a, b = a[..., crop_border:-crop_border, crop_border:-crop_border], b[..., crop_border:-crop_border, crop_border:-crop_border]
+    ya, yb = to_y_channel(a)[0].to(torch.float64), to_y_channel(b)[0].to(torch.float64)
+    return float(_ssim_planes(ya, yb, (0.01 * 255) ** 2, (0.03 * 255) ** 2, "replicate", False).mean())
+
+
+def psnr_y(img1_bgr, img2_bgr, crop_border=0):
+    """calculate_psnr(test_y_channel=True), psnr_ssim.py:52-61: MSE of the two Y planes (float32 values, float64 mean)."""
+    a, b = img1_bgr.to(torch.float64), img2_bgr.to(torch.float64)
+    if crop_border:
+        a, b = a[..., crop_border:-crop_border, crop_border:-crop_border], b[..., crop_border:-crop_border, crop_border:-crop_border]
+    ya, yb = to_y_channel(a), to_y_channel(b)
+    d = (ya - yb)                                                                # float32 difference (numpy float32 arrays, :58)
+    mse = float((d * d).mean(dtype=torch.float32))
+    if mse == 0:
+        return float("inf")
+    peak = 1.0 if ya.max().item() <= 1 else 255.0
+    return 20.0 * math.log10(peak / math.sqrt(mse))
+
+
 def psnr(a, b, peak=1.0):
     """20*log10(peak/sqrt(mse)) (basicsr/metrics/psnr_ssim.py:59-63)."""
     mse = torch.mean((a.double() - b.double()) ** 2).item()

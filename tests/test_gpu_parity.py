@@ -442,6 +442,14 @@ def test_metrics_kernels(A):
     b = (a + 0.02 * torch.randn(a.shape, generator=g)).clamp(0, 1)
     assert abs(metrics.calculate_psnr(dev(a), dev(b)) - O.calculate_psnr(a[0], b[0])) < 1e-9
     assert metrics.calculate_psnr(dev(a), dev(a)) == float("inf")
+    # the remaining branches: Y channel (PSNR and _ssim_cly) and the 2-D SSIM, float64 on the device like the reference's numpy path
+    for name, x, y, ref in _metric_cases("metrics2d"):
+        b = ref["crop_border"]
+        assert abs(metrics.calculate_ssim(dev(x), dev(y), b, ssim3d=False) - ref["ssim_2d"]) < 1e-10, name
+        if "psnr_y" in ref:
+            assert torch.equal(metrics.to_y_channel(dev(x)).cpu()[0], ref["ych"]), name
+            assert abs(metrics.calculate_psnr(dev(x), dev(y), b, test_y_channel=True) - ref["psnr_y"]) < 1e-5, name
+            assert abs(metrics.calculate_ssim(dev(x), dev(y), b, test_y_channel=True) - ref["ssim_y"]) < 1e-10, name
 
 
 @pytest.mark.parametrize("K,N,H,W", [(32, 152, 736, 1280), (32, 86, 736, 1280), (64, 304, 368, 640), (64, 172, 368, 640),

@@ -200,14 +200,15 @@ def test_grids_against_reference_methods(case):
     assert torch.equal(merged, torch.from_numpy(z[case + "_merged"]))
 
 
-def _metric_cases():
+def _metric_cases(which="metrics"):
     import json
     import os
     import numpy as np
     from common import GOLDEN
-    z = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    z = np.load(os.path.join(GOLDEN, which + ".npz"))
     cases = json.loads(bytes(z["cases_json"]).decode())
-    return [(k, torch.from_numpy(z[k + "_x"]), torch.from_numpy(z[k + "_y"]), v) for k, v in cases.items()]
+    return [(k, torch.from_numpy(z[k + "_x"]), torch.from_numpy(z[k + "_y"]), dict(v, ych=torch.from_numpy(z[k + "_ych"]) if k + "_ych" in z.files else None))
+            for k, v in cases.items()]
 
 
 def test_metrics_against_reference_functions():
@@ -216,6 +217,18 @@ def test_metrics_against_reference_functions():
     for name, x, y, ref in _metric_cases():
         assert abs(O.calculate_psnr(x, y, ref["crop_border"]) - ref["psnr"]) < 1e-9, name
         assert abs(O.ssim_3d(x, y, ref["crop_border"]) - ref["ssim"]) < 1e-6, name
+
+
+def test_metrics_2d_and_y_channel_against_reference_functions():
+    """The other branches of the same functions - test_y_channel (to_y_channel, _ssim_cly) and ssim3d=False (_ssim) - against the
+    values the reference's function bodies produce (tests/golden/make_golden_metrics2d.py)."""
+    for name, x, y, ref in _metric_cases("metrics2d"):
+        b = ref["crop_border"]
+        assert abs(O.ssim_2d(x, y, b) - ref["ssim_2d"]) < 1e-12, name
+        if "psnr_y" in ref:
+            assert torch.equal(O.to_y_channel(x)[0], ref["ych"]), name
+            assert abs(O.psnr_y(x, y, b) - ref["psnr_y"]) < 1e-5, name          # (the reference averages float32 squares: summation order)
+            assert abs(O.ssim_y(x, y, b) - ref["ssim_y"]) < 1e-12, name
 
 
 # --------------------------------------------------------------------------------------------------------------
