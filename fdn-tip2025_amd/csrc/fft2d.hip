@@ -178,6 +178,11 @@ bool get_rader(int p, Rader* out) {
 // device: Stockham passes over sequences held in LDS
 //   element idx of sequence s lives at  s*ss + idx*es
 // ------------------------------------------------------------------------------------------
+// i / d for the index ranges of these kernels without the ~25-instruction integer division sequence: with r = 1.0f / d,
+// floor((i + 0.5) * r) is exact while i < 2^22 and d < 2^12 (the rounding error of the product, ~1.2e-7 * i / d, stays below the
+// 0.5 / d margin the half adds).  The passes used to spend most of their vector instructions on `job / nseq` and `i % Ns`.
+__device__ __forceinline__ int fdiv(int i, float r) { return (int)(((float)i + 0.5f) * r); }
+
 template <bool INV>
 __device__ __forceinline__ float2 twd(const float2* __restrict__ tw, int idx) {
     const float2 w = tw[idx];
@@ -232,11 +237,12 @@ __device__ void fft_pass_reg(const float2* src, float2* dst, int N, int Ns, int 
 #pragma unroll
     for (int t = 1; t <= (R - 1) / 2; ++t) wR[t - 1] = twd<INV>(tw, t * twr);
     const int jobs = T * nseq;
+    const float r_nseq = 1.0f / (float)nseq, r_T = 1.0f / (float)T, r_Ns = 1.0f / (float)Ns;
     for (int job = threadIdx.x; job < jobs; job += NT) {
         int i, s;
-        if (seq_fast) { i = job / nseq; s = job - i * nseq; }
-        else { s = job / T; i = job - s * T; }
-        const int k = i % Ns;
+        if (seq_fast) { i = fdiv(job, r_nseq); s = job - i * nseq; }
+        else { s = fdiv(job, r_T); i = job - s * T; }
+        const int k = i - fdiv(i, r_Ns) * Ns;
         const int j = (i - k) * R + k;
         const float2* sp = src + s * ss;
         float2* dp = dst + s * ss;
@@ -260,6 +266,7 @@ __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, i
     const int L = Ns * R;
     const int tws = tab_mul * (N / L);        // W_L^e = tw[e * tws]
     const int jobs = T * nseq;
+    const float r_nseq = 1.0f / (float)nseq, r_T = 1.0f / (float)T, r_Ns = 1.0f / (float)Ns, r_jobs = 1.0f / (float)jobs;
     switch (R) {
         case 3: fft_pass_reg<INV, 3>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
         case 5: fft_pass_reg<INV, 5>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
@@ -272,11 +279,11 @@ __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, i
         // gather form, one output element per job: out[m] = sum_r in[i + r*T] * W_L^{r*m}
         const int jobs2 = jobs * R;
         for (int job2 = threadIdx.x; job2 < jobs2; job2 += NT) {
-            const int o = job2 / jobs, job = job2 - o * jobs;
+            const int o = fdiv(job2, r_jobs), job = job2 - o * jobs;
             int i, s;
-            if (seq_fast) { i = job / nseq; s = job - i * nseq; }
-            else { s = job / T; i = job - s * T; }
-            const int k = i % Ns;
+            if (seq_fast) { i = fdiv(job, r_nseq); s = job - i * nseq; }
+            else { s = fdiv(job, r_T); i = job - s * T; }
+            const int k = i - fdiv(i, r_Ns) * Ns;
             const int j = (i - k) * R + k;
             const float2* sp = src + s * ss;
             const int m = k + o * Ns;              // output position inside the length-L block
@@ -296,9 +303,9 @@ __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, i
     }
     for (int job = threadIdx.x; job < jobs; job += NT) {
         int i, s;
-        if (seq_fast) { i = job / nseq; s = job - i * nseq; }
-        else { s = job / T; i = job - s * T; }
-        const int k = i % Ns;
+        if (seq_fast) { i = fdiv(job, r_nseq); s = job - i * nseq; }
+        else { s = fdiv(job, r_T); i = job - s * T; }
+        const int k = i - fdiv(i, r_Ns) * Ns;
         const int j = (i - k) * R + k;
         const float2* sp = src + s * ss;
         float2* dp = dst + s * ss;
@@ -359,13 +366,14 @@ __device__ void fft_pass_inplace(float2* buf, int N, int Ns, int nseq, const flo
     const int L = Ns * R;
     const int tws = N / L, twr = N / R;
     const int jobs = T * nseq;
+    const float r_nseq = 1.0f / (float)nseq, r_Ns = 1.0f / (float)Ns;
     float2 u[JMAX][R];
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
         const int job = threadIdx.x + NT * j;
         if (job < jobs) {
-            const int i = job / nseq, s = job - i * nseq;
-            const int k = i % Ns;
+            const int i = fdiv(job, r_nseq), s = job - i * nseq;
+            const int k = i - fdiv(i, r_Ns) * Ns;
 #pragma unroll
             for (int r = 0; r < R; ++r) u[j][r] = buf[s + (i + r * T) * nseq];
             if (k) {
@@ -379,8 +387,8 @@ __device__ void fft_pass_inplace(float2* buf, int N, int Ns, int nseq, const flo
     for (int j = 0; j < JMAX; ++j) {
         const int job = threadIdx.x + NT * j;
         if (job < jobs) {
-            const int i = job / nseq, s = job - i * nseq;
-            const int k = i % Ns;
+            const int i = fdiv(job, r_nseq), s = job - i * nseq;
+            const int k = i - fdiv(i, r_Ns) * Ns;
             float2* dp = buf + s + ((i - k) * R + k) * nseq;
             if (R == 2) {
                 dp[0] = make_float2(u[j][0].x + u[j][1].x, u[j][0].y + u[j][1].y);
@@ -521,9 +529,10 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
     }
     // split: X[k] = E[k] + W_N^k O[k],  E = (Z[k]+conj Z[M-k])/2,  O = -i (Z[k]-conj Z[M-k])/2
     const int tw1 = p.tab_mul / 2;              // table is W_W^t:  tab_mul = W / M = 2  -> stride 1
+    const float r_Wf = 1.0f / (float)Wf;
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < nrow * Wf; idx += NT) {
-        const int s = idx / Wf, k = idx - s * Wf;
+        const int s = fdiv(idx, r_Wf), k = idx - s * Wf;
         const float2 zk = Z[s * M + (k == M ? 0 : k)];
         const float2 zc = Z[s * M + (k == 0 ? 0 : M - k)];
         const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
@@ -557,14 +566,16 @@ __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict
     const int nrow = (int)min((long)rpb, R - row0);
     const int tw1 = p.tab_mul / 2;
     constexpr int UL = 4;
+    const float r_M = 1.0f / (float)M, r_H = 1.0f / (float)H;
     for (int base = threadIdx.x; base < rpb * M; base += NT * UL) {
       float2 xks[UL], xcs[UL];
 #pragma unroll
       for (int u = 0; u < UL; ++u) {                               // batched, unconditional loads (clamped row)
         const int idx = base + NT * u;
-        const int s = min(idx / M, nrow - 1), k = idx % M;
+        const int s0 = fdiv(idx, r_M), k = idx - s0 * M;
+        const int s = min(s0, nrow - 1);
         const long row = row0 + s;
-        const long plane = row / H, h = row - plane * H;
+        const long plane = row < (1L << 22) ? (long)fdiv((int)row, r_H) : row / H, h = row - plane * H;
         const float2* src = in + plane * in_plane_stride + h * in_ws;
         xks[u] = src[k];
         xcs[u] = src[M - k];
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(NT) void irfft_rows_kernel(const float2* __restrict
       for (int u = 0; u < UL; ++u) {
         const int idx = base + NT * u;
         if (idx >= rpb * M) continue;
-        const int s = idx / M, k = idx - s * M;
+        const int s = fdiv(idx, r_M), k = idx - s * M;
         float2 z = make_float2(0.f, 0.f);
         if (s < nrow) {
             float2 xk = xks[u], xc = xcs[u];
