@@ -599,6 +599,7 @@ __device__ __forceinline__ const float* byte_advance(const float* p, long bytes)
 template <int NCH, int PRO, int VEC, bool TAIL, bool XBF = false, bool OBF = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_smallk_vec_kernel(fdn_conv1x1_desc d, Geo g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(VEC == 2, "only the 8-byte-lane form is validated: a 16-byte-lane build gave wrong results at full size (round 1) and is not shipped");
     typedef typename VecT<VEC>::type vf;
     constexpr int NT = 256, NWV = 4;
     constexpr int Kp = NCH * KC, KS = NCH * 16;
@@ -1543,8 +1544,7 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         const int ntiles = (d.N + 31) / 32;
         if (d.K <= KC) {
             if (d.pro == FDN_PRO_LN) return launch_smallk_vec<1, FDN_PRO_LN, 2>(d, s);       // (16-byte lanes measure the same here)
-            return launch_smallk_vec<1, FDN_PRO_NONE, 2>(d, s);       // (the 16-byte-lane instantiation miscomputes at full size once the
-                                                                      //  bias table read joins its epilogue - not understood; 8-byte lanes measure the same)
+            return launch_smallk_vec<1, FDN_PRO_NONE, 2>(d, s);       // (8-byte lanes only: the kernel static_asserts VEC == 2)
         }
         if ((2UL * 2 * KC + 2UL * KC * (ntiles * 32 + 1)) * sizeof(float) <= 52 * 1024) {
             if (d.pro == FDN_PRO_LN) return launch_smallk_vec<2, FDN_PRO_LN, 2>(d, s);
