@@ -48,21 +48,47 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return act == FDN_ACT_SIGMOID ? 1.0f / (1.0f + expf(-v)) : gelu_erf(v);
 }
 
-// sin and cos together, ~1 ulp for |x| < 8192 (three-constant Cody-Waite reduction by pi/2, then the classic
-// single-precision minimax polynomials on [-pi/4, pi/4]); larger arguments take the library path.  The
-// library sincosf costs ~4x the instructions because it carries the Payne-Hanek reduction inline.
+// sin and cos together, ~1 ulp over the whole float range and without a library call (a call site costs the caller its
+// register allocation: the column FFT kernel evaluates 32 of these in straight-line code).
+//   |x| < 8192 : three-constant Cody-Waite reduction by pi/2 in fp32
+//   otherwise  : |x| = m * 2^e with a 24-bit integer m, and x * 2/pi mod 4 = m * T[e] mod 4 with T[e] = (2^e * 2/pi) mod 4
+//                tabulated as double-double (sincos_table.inc, e = -10 .. 104): one exact fp64 product instead of a
+//                Payne-Hanek loop; the reduced argument is good to ~2^-60.  Inf / NaN give NaN.
+// then the classic single-precision minimax polynomials on [-pi/4, pi/4].
+static __device__ const double fdn_two_over_pi_mod4[115][2] = {
+#include "sincos_table.inc"
+};
+// FULL = false: the fp32 reduction only, valid for |x| < 8192 (callers that evaluate many arguments in straight-line code
+// run this form, note whether any argument was out of range and redo that rare case with the full form)
+template <bool FULL = true>
 __device__ __forceinline__ void fdn_sincos(float x, float* sn, float* cs) {
-    if (!(fabsf(x) < 8192.0f)) { sincosf(x, sn, cs); return; }
-    const float k = rintf(x * 0.63661977236758134308f);
-    float r = fmaf(k, -1.5707962513e+0f, x);
-    r = fmaf(k, -7.5497894159e-08f, r);
-    r = fmaf(k, -5.3903029534e-15f, r);
+    float r;
+    int q;
+    if (!FULL || __builtin_expect(fabsf(x) < 8192.0f, 1)) {
+        const float k = rintf(x * 0.63661977236758134308f);
+        r = fmaf(k, -1.5707962513e+0f, x);
+        r = fmaf(k, -7.5497894159e-08f, r);
+        r = fmaf(k, -5.3903029534e-15f, r);
+        q = (int)k;
+    } else {
+        const unsigned bits = __float_as_uint(x) & 0x7FFFFFFFu;
+        const int eb = (int)(bits >> 23);                               // >= 140: |x| = m * 2^(eb - 150)
+        const double m = (double)(int)((bits & 0x7FFFFFu) | 0x800000u);
+        const int idx = (eb > 254 ? 254 : eb) - 140;
+        const double fh = fdn_two_over_pi_mod4[idx][0], fl = fdn_two_over_pi_mod4[idx][1];
+        const double p = m * fh, pe = fma(m, fh, -p);                   // p + pe = m * fh exactly, p < 2^26
+        const double kq = rint(p);
+        const double fr = (p - kq) + fma(m, fl, pe);                    // |fr| <= 1/2 (+ 2^-27)
+        r = (float)(fr * 1.57079632679489661923);
+        q = (int)kq;
+        if (x < 0.0f) { r = -r; q = -q; }
+        if (eb == 255) r = __uint_as_float(0x7FC00000u);
+    }
     const float r2 = r * r;
     const float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
     const float s0 = fmaf(r * r2, ps, r);
     const float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
     const float c0 = fmaf(r2 * r2, pc, fmaf(-0.5f, r2, 1.0f));
-    const int q = (int)k;
     const float a = (q & 1) ? c0 : s0, b = (q & 1) ? s0 : c0;
     *sn = (q & 2) ? -a : a;
     *cs = ((q + 1) & 2) ? -b : b;

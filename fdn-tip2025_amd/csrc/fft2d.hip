@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "fft_regs.hpp"
 
 namespace {
 
@@ -813,6 +814,292 @@ __global__ __launch_bounds__(NT, (INPL ? 2 : 1)) void fft_cols_kernel(ColArgs a,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Columns of length H = R * P (R an odd prime, P = 8 / 16 / 32) with a compile-time plan: 736 / 368 / 184 rows of the 720p
+// pyramid (R = 23), 544 / 272 / 136 of 1080p (R = 17).  Cooley-Tukey with n = P n1 + n2, k = k1 + R k2:
+//   1  thread (n2, column) loads x[P n1 + n2], n1 < R, straight into registers and runs the R-point DFT over n1
+//   2  -> LDS  Y[k1][n2][column]                                                        (barrier)
+//   3  thread (k1, column group) takes the P values of its 32 / P columns, multiplies by W_H^{n2 k1} and runs the P-point
+//      FFT over n2 in registers (decimation in frequency: bit-reversed k2) -> the bins h = k1 + R k2 of those columns
+//   4  the pointwise spectral operation on those registers (FCAFFN modulation / abs + angle out / polar in)
+//   5  inverse P-point FFT over k2 (decimation in time: takes the bit-reversed order as it is), * W_H^{-n2 k1}
+//   6  -> LDS, same cells                                                               (barrier)
+//   7  thread (n2, column) runs the inverse R-point DFT over k1 and stores x[P n1 + n2]
+// Two barriers and two LDS round trips per element (the generic in-place passes: 8 barriers-pairs and 18 LDS accesses for
+// 736 = 23*4*4*2), no index arithmetic in the passes, all roots of unity inside the transforms are instruction constants.
+// A workgroup owns 256 / P adjacent columns, so every step-1 wave is full; step 3 has R * 8 jobs (184 of 256 threads for R = 23):
+// the idle wave rotates with the workgroup index.
+// ------------------------------------------------------------------------------------------
+using fftr::f2;
+using fftr::sfor;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cols_rsrc(const void* base, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7FFFFFFFL ? 0x7FFFFFFFL : bytes), 0x00020000);
+}
+__device__ __forceinline__ f2 bload_f2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const fdn_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return f2{__uint_as_float(u.x), __uint_as_float(u.y)};
+}
+__device__ __forceinline__ void bstore_f2(f2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, voff, soff, 0);
+}
+
+template <int R, int P, int MODE>
+__global__ __launch_bounds__(256, 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
+    constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = 256 + 8, NJ = R * NG;
+    static_assert(TC / CJ == NG, "8 column groups");
+    __shared__ f2 Y[R * KS];
+    __shared__ f2 twl[P * R];                       // twl[n2 * R + k1] = W_H^{n2 k1}
+    const int tid = threadIdx.x, Wf = a.Wf;
+    for (int i = tid; i < P * R; i += 256) twl[i] = f2{twT[i].x, twT[i].y};
+    // work order: every XCD walks a contiguous run of items ordered (batch, chunk of 8 channels, column tile, channel in chunk):
+    // the tiles either side of a shared 128-byte line run within a few workgroups of each other on one L2, and the guidance
+    // records of a tile (shared by all channels of a batch item) are re-read from memory once per chunk only
+    int plane, col0;
+    {
+        const int ntile = (Wf + TC - 1) / TC;
+        const long total = (long)ntile * a.planes, per_xcd = (total + 7) / 8;
+        const long w = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (w >= total) return;                                              // uniform: before any barrier
+        const int C = a.C, CH = (C % 8 == 0) ? 8 : 1;
+        const long grp = w / CH;
+        const int ci = (int)(w - grp * CH);
+        const long rest = grp / ntile;
+        col0 = (int)(grp - rest * ntile) * TC;
+        const int nchunk = C / CH;
+        const long b = rest / nchunk;
+        plane = (int)(b * C + (rest - b * nchunk) * CH + ci);
+    }
+    const int c = tid & (TC - 1), n2 = tid / TC;
+    const bool live = col0 + c < Wf;
+    const int col = live ? col0 + c : Wf - 1;                                // dead lanes shadow the last column (columns never mix)
+    const long plane_bins = (long)H * Wf;                                     // < 2^28: byte offsets inside a plane fit 32 bits
+    const __amdgpu_buffer_rsrc_t rz = cols_rsrc(a.z + (long)plane * plane_bins, plane_bins * 8);
+    const unsigned zoff = (unsigned)(n2 * Wf + col) * 8u, zstep = (unsigned)(P * Wf) * 8u;
+
+    if (MODE != COL_INV_POLAR) {
+        f2 u[R];
+        sfor<0, R>([&](auto n1) { u[decltype(n1)::value] = bload_f2(rz, zoff, (unsigned)decltype(n1)::value * zstep); });
+        fftr::dft_odd_c<R, false>(u);
+        sfor<0, R>([&](auto k1) { Y[decltype(k1)::value * KS + tid] = u[decltype(k1)::value]; });
+    }
+
+    const int jt = (tid + 64 * (int)(blockIdx.x >> 3)) & 255;
+    const bool worker = jt < NJ;
+    const int k1 = worker ? jt >> 3 : 0, cg = jt & 7;
+    // column of value slot q (q / P = column inside the group): clamped like `col`
+    unsigned binq[CJ];                              // k1 * Wf + column: bin offset of slot (cc, k2 = 0) inside a plane
+    bool liveq[CJ];
+#pragma unroll
+    for (int cc = 0; cc < CJ; ++cc) {
+        liveq[cc] = col0 + cg * CJ + cc < Wf;
+        binq[cc] = (unsigned)(k1 * Wf + (liveq[cc] ? col0 + cg * CJ + cc : Wf - 1));
+    }
+    const unsigned kstep = (unsigned)(R * Wf);      // bins between k2 and k2 + 1
+    constexpr int NB = 8, BS = 32 / NB;             // guidance records in batches of 4, one batch in flight ahead of the arithmetic
+    fdn_u32x4 g0[2][BS];
+    fdn_u32x2 g1[2][BS];
+    __amdgpu_buffer_rsrc_t rg = rz;
+    float wa0 = 0, wa1 = 0, wa2 = 0, wp0 = 0, wp1 = 0, wp2 = 0;
+    auto gload = [&](auto bb) __attribute__((always_inline)) {
+        constexpr int Bb = decltype(bb)::value;
+        sfor<0, BS>([&](auto i) {
+            constexpr int q = Bb * BS + decltype(i)::value, cc = q / P, k2 = fftr::brev(q % P, P);
+            g0[Bb & 1][decltype(i)::value] = __builtin_amdgcn_raw_buffer_load_b128(rg, binq[cc] * 32u, (unsigned)k2 * kstep * 32u, 0);
+            g1[Bb & 1][decltype(i)::value] = __builtin_amdgcn_raw_buffer_load_b64(rg, binq[cc] * 32u, (unsigned)k2 * kstep * 32u + 16u, 0);
+        });
+    };
+    if (MODE == COL_FCAFFN) {
+        const int b = plane / a.C, ch = plane - b * a.C;
+        wa0 = a.wxa[ch * 3]; wa1 = a.wxa[ch * 3 + 1]; wa2 = a.wxa[ch * 3 + 2];
+        wp0 = a.wxp[ch * 3]; wp1 = a.wxp[ch * 3 + 1]; wp2 = a.wxp[ch * 3 + 2];
+        rg = cols_rsrc(a.guide + (long)b * plane_bins * 2, plane_bins * 32);
+        if (worker) gload(std::integral_constant<int, 0>{});
+    }
+    __syncthreads();
+
+    if (worker) {
+        f2 v[32];                                   // slot q = cc * P + (n2 | bit-reversed k2)
+        f2* yb = Y + k1 * KS + cg * CJ;
+        // steps 3 and 4 for the FCAFFN mode.  FULL = false evaluates the 32 sincos with the fp32 range reduction only
+        // (branch-free: 135 registers; with a range check at every site the allocator spills) and reports whether any
+        // phase was outside its range; that case is redone from the LDS copy with the full-range form.
+        auto forward = [&]() __attribute__((always_inline)) {
+            sfor<0, P>([&](auto n) {
+                constexpr int N2 = decltype(n)::value;
+#pragma unroll
+                for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = yb[N2 * TC + cc];
+                if constexpr (N2 > 0) {
+                    const f2 w = twl[N2 * R + k1];
+#pragma unroll
+                    for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = fftr::cmul(v[cc * P + N2], w);
+                }
+            });
+#pragma unroll
+            for (int cc = 0; cc < CJ; ++cc) fftr::fft_dif<P, false>(v + cc * P);
+        };
+        auto modulate = [&](auto full) __attribute__((always_inline)) -> bool {
+            constexpr bool FULL = decltype(full)::value;
+            bool big = false;
+            sfor<0, NB>([&](auto bb) {
+                constexpr int Bb = decltype(bb)::value;
+                if constexpr (Bb + 1 < NB) gload(std::integral_constant<int, Bb + 1>{});
+                sfor<0, BS>([&](auto i) {
+                    constexpr int I = decltype(i)::value, q = Bb * BS + I;
+                    const fdn_u32x4 ga = g0[Bb & 1][I];
+                    const fdn_u32x2 gp = g1[Bb & 1][I];
+                    const float A_ = wa0 * __uint_as_float(ga.x) + wa1 * __uint_as_float(ga.y) + wa2 * __uint_as_float(ga.z);   // conv1_xa(x_high)
+                    const float ph = wp0 * __uint_as_float(ga.w) + wp1 * __uint_as_float(gp.x) + wp2 * __uint_as_float(gp.y);   // conv1_xp(xp2)
+                    float sn, cs;
+                    fdn_sincos<FULL>(ph, &sn, &cs);
+                    if (!FULL) big |= !(fabsf(ph) < 8192.0f);
+                    const f2 r = f2{rd1(v[q].x), rd1(v[q].y)};                        // FDN_arch.py:412
+                    v[q] = fftr::cmul(r, f2{A_ * cs, -A_ * sn});                      // |z| A e^{i(ang z - ph)}  :413-417
+                });
+            });
+            return big;
+        };
+        if (MODE != COL_INV_POLAR) forward();
+        if (MODE == COL_FWD) {
+            const bool evenH = (H % 2) == 0;
+            const __amdgpu_buffer_rsrc_t ra = cols_rsrc(a.out_abs ? a.out_abs + (long)plane * plane_bins : nullptr, a.out_abs ? plane_bins * 4 : 0);
+            const __amdgpu_buffer_rsrc_t rp = cols_rsrc(a.out_ang ? a.out_ang + (long)plane * plane_bins : nullptr, a.out_ang ? plane_bins * 4 : 0);
+            sfor<0, 32>([&](auto qq) {
+                constexpr int q = decltype(qq)::value, cc = q / P, k2 = fftr::brev(q % P, P);
+                if (liveq[cc]) {
+                    f2 x = v[q];
+                    const int cl = (int)binq[cc] - k1 * Wf;
+                    if (a.fix_real && (cl == 0 || cl == Wf - 1) && k1 == 0 && (k2 == 0 || (evenH && 2 * k2 == P))) x.y = 0.0f;
+                    if (a.rd_before) x = f2{rd1(x.x), rd1(x.y)};
+                    // (a null plane has a zero-length descriptor: the store is dropped)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sqrtf(x.x * x.x + x.y * x.y)), ra, binq[cc] * 4u, (unsigned)k2 * kstep * 4u, 0);
+                    if (a.out_ang) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(atan2f(x.y, x.x)), rp, binq[cc] * 4u, (unsigned)k2 * kstep * 4u, 0);
+                }
+            });
+            return;                                 // no barrier follows in this mode
+        }
+        if (MODE == COL_FCAFFN) {
+            if (__builtin_expect(modulate(std::false_type{}), 0)) {
+                asm volatile("" ::: "memory");      // start over from memory: nothing of the first pass is kept alive for this one
+                forward();                          // Y still holds the step-2 values of this thread's cells
+                gload(std::integral_constant<int, 0>{});
+                modulate(std::true_type{});
+            }
+        }
+        if (MODE == COL_INV_POLAR) {
+            const long in_bins = (long)a.Hin * a.Wfin;
+            const __amdgpu_buffer_rsrc_t rm = cols_rsrc(a.in_mag + (long)plane * in_bins, in_bins * 4);
+            const __amdgpu_buffer_rsrc_t rp = cols_rsrc(a.in_pha + (long)plane * in_bins, in_bins * 4);
+            unsigned inq[CJ];
+#pragma unroll
+            for (int cc = 0; cc < CJ; ++cc) inq[cc] = (unsigned)(k1 * a.Wfin + ((int)binq[cc] - k1 * Wf)) * 4u;
+            const unsigned instep = (unsigned)(R * a.Wfin) * 4u;
+            sfor<0, NB>([&](auto bb) {
+                constexpr int Bb = decltype(bb)::value;
+                float mg[BS], ph[BS];
+                sfor<0, BS>([&](auto i) {
+                    constexpr int I = decltype(i)::value, q = Bb * BS + I, cc = q / P, k2 = fftr::brev(q % P, P);
+                    mg[I] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, inq[cc], (unsigned)k2 * instep, 0));
+                    ph[I] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, inq[cc], (unsigned)k2 * instep, 0));
+                });
+                sfor<0, BS>([&](auto i) {
+                    constexpr int I = decltype(i)::value, q = Bb * BS + I;
+                    float sn, cs;
+                    fdn_sincos(ph[I], &sn, &cs);
+                    v[q] = f2{mg[I] * cs, mg[I] * sn};                                // FDN_arch.py:95-97
+                });
+            });
+        }
+#pragma unroll
+        for (int cc = 0; cc < CJ; ++cc) fftr::fft_dit<P, true>(v + cc * P);
+        asm volatile("" ::: "memory");              // re-read the twiddles: carrying the forward copies across the modulation costs 62 registers
+        sfor<0, P>([&](auto n) {
+            constexpr int N2 = decltype(n)::value;
+            if constexpr (N2 > 0) {
+                const f2 w = twl[N2 * R + k1];
+#pragma unroll
+                for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = fftr::cmulc(v[cc * P + N2], w);
+            }
+#pragma unroll
+            for (int cc = 0; cc < CJ; ++cc) yb[N2 * TC + cc] = v[cc * P + N2];
+        });
+    } else if (MODE == COL_FWD) {
+        return;
+    }
+    __syncthreads();
+    {
+        f2 u[R];
+        sfor<0, R>([&](auto k) { u[decltype(k)::value] = Y[decltype(k)::value * KS + tid]; });
+        fftr::dft_odd_c<R, true>(u);
+        if (live) sfor<0, R>([&](auto n1) { bstore_f2(u[decltype(n1)::value], rz, zoff, (unsigned)decltype(n1)::value * zstep); });
+    }
+}
+
+// transposed twiddles of the R x P split: tab[n2 * R + k1] = W_H^{n2 k1}, exact on the axes
+const float2* get_table_rp(int R, int P) {
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int key = -(R * 1024 + P);
+    auto it = g_tables.find({devid, key});
+    if (it != g_tables.end()) return it->second;
+    const int H = R * P;
+    std::vector<float2> h((size_t)R * P);
+    for (int n2 = 0; n2 < P; ++n2)
+        for (int k1 = 0; k1 < R; ++k1) {
+            const long t = ((long)n2 * k1) % H;
+            double c, s;
+            if ((4 * t) % H == 0) {
+                const int q = (int)((4 * t) / H);
+                c = (q == 0) ? 1.0 : (q == 2 ? -1.0 : 0.0);
+                s = (q == 1) ? 1.0 : (q == 3 ? -1.0 : 0.0);
+            } else {
+                const double ang = 2.0 * M_PI * (double)t / (double)H;
+                c = cos(ang); s = sin(ang);
+            }
+            float2 w = make_float2((float)c, (float)(-s) + 0.0f);
+            if (w.y == 0.0f) w.y = 0.0f;
+            if (w.x == 0.0f) w.x = 0.0f;
+            h[(size_t)n2 * R + k1] = w;
+        }
+    float2* d = nullptr;
+    if (hipMalloc(&d, sizeof(float2) * h.size()) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    g_tables[{devid, key}] = d;
+    return d;
+}
+
+template <int R, int P, int MODE>
+int launch_cols_rp(ColArgs a, long planes, fdn_stream_t stream) {
+    const float2* tw = get_table_rp(R, P);
+    if (!tw) return FDN_ERR_LAUNCH;
+    a.planes = planes;
+    if (a.C <= 0 || planes % a.C != 0) a.C = 1;
+    constexpr int TC = 256 / P;
+    const long total = (long)cdiv(a.Wf, TC) * planes, per_xcd = (total + 7) / 8;
+    if (per_xcd * 8 > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((fft_cols_rp_kernel<R, P, MODE>), dim3((unsigned)(per_xcd * 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a, tw);
+    return fdn_launch_status();
+}
+
+// the compile-time plans: H = 23 * {32, 16, 8} (720p pyramid), 17 * {32, 16, 8} (1080p levels 2, 3 and 544-row inputs)
+template <int MODE>
+int launch_cols_planned(const ColArgs& a, long planes, fdn_stream_t stream, bool* done) {
+    *done = true;
+    switch (a.H) {
+        case 23 * 32: return launch_cols_rp<23, 32, MODE>(a, planes, stream);
+        case 23 * 16: return launch_cols_rp<23, 16, MODE>(a, planes, stream);
+        case 23 * 8: return launch_cols_rp<23, 8, MODE>(a, planes, stream);
+        case 17 * 32: return launch_cols_rp<17, 32, MODE>(a, planes, stream);
+        case 17 * 16: return launch_cols_rp<17, 16, MODE>(a, planes, stream);
+        case 17 * 8: return launch_cols_rp<17, 8, MODE>(a, planes, stream);
+        default: break;
+    }
+    *done = false;
+    return FDN_OK;
+}
+
 bool plan_big(const Plan& p) {
     for (int i = 0; i < p.nst; ++i)
         if (p.radix[i] == 17 || p.radix[i] == 23) return true;
@@ -874,6 +1161,11 @@ int launch_cols_k(ColArgs a, const Plan& p, long planes, size_t lds, fdn_stream_
 
 template <int MODE>
 int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
+    {
+        bool done = false;
+        const int e = launch_cols_planned<MODE>(a, planes, stream, &done);
+        if (done) return e;
+    }
     Plan p;
     if (!make_plan(a.H, a.H, &p)) return FDN_ERR_UNSUPPORTED;
     const int itc = inplace_tc(p, a.H);
@@ -896,7 +1188,28 @@ int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
 
 extern "C" int fdn_fft_prepare(int n) {
     FDN_CHECK_ARG(n > 0);
+    for (int R : {23, 17})
+        for (int P : {32, 16, 8})
+            if (n == R * P && !get_table_rp(R, P)) return FDN_ERR_LAUNCH;      // column lengths with a compile-time plan
     return get_table(n) ? FDN_OK : FDN_ERR_LAUNCH;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void sincos_kernel(const float* __restrict__ x, float* __restrict__ sn, float* __restrict__ cs, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        float s, c;
+        fdn_sincos(x[i], &s, &c);
+        sn[i] = s;
+        cs[i] = c;
+    }
+}
+}  // namespace
+
+extern "C" int fdn_sincos_f32(const float* x, float* sn, float* cs, long n, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && sn && cs && n > 0 && n < (1L << 39));
+    hipLaunchKernelGGL(sincos_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, sn, cs, n);
+    return fdn_launch_status();
 }
 
 extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t stream) {

@@ -331,6 +331,13 @@ def irfft_rows(z, H, W, scale, res=None, alpha=0.0, out=None):
     return out
 
 
+def sincos(x):
+    """(sin x, cos x) as the polar <-> complex steps of the column kernels evaluate them (fdn_sincos_f32; test hook)."""
+    sn, cs = torch.empty_like(x), torch.empty_like(x)
+    check(lib().fdn_sincos_f32(_flat(x, "x"), _flat(sn, "sn"), _flat(cs, "cs"), ctypes.c_long(x.numel()), stream()), "fdn_sincos_f32")
+    return sn, cs
+
+
 def pack_guidance(amp, pha):
     """(amp, pha) [B,3,H,Wf] -> one 32-byte record per bin [B,H,Wf,8] (fdn_pack_guidance).  The guidance of a
     level is shared by all its encoder blocks, so the packed copy is memoised on the amp tensor object."""

@@ -155,6 +155,10 @@ int fdn_img_mod_maps(const float* img, const float* w1_mul, const float* w3_mul,
  * Any even W and any H are accepted (mixed radix; large primes use an O(N*R) gather pass).
  * fdn_fft_prepare(n): build the immutable twiddle table of length n now (else first use does). */
 int fdn_fft_prepare(int n);
+/* sn[i] = sin(x[i]), cs[i] = cos(x[i]) with the library's own range reduction (what the polar <-> complex steps of the column
+ * kernels evaluate for torch.cos / torch.sin at FDN_arch.py:95-97, :414-416): ~1 ulp over the whole float range, NaN for
+ * Inf / NaN.  Exposed so the tests can pin it against a float64 reference at large arguments. */
+int fdn_sincos_f32(const float* x, float* sn, float* cs, long n, fdn_stream_t stream);
 /* r2c along rows: in [rows][W] real -> out_c [rows][W/2+1] complex. */
 int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t stream);
 /* c2r along rows: spectrum rows of `in_row_bins` bins (>= W/2+1; leading-slice crop of

@@ -1,0 +1,128 @@
+"""GPU tests of the column FFT kernels with a compile-time plan (H = 23 * {32,16,8}: the 720p pyramid, 17 * {32,16,8}: 1080p
+levels 2-3) against torch.fft in float64, in all three modes, with partial column tiles, and of the sin / cos the modulation
+evaluates (large arguments take the table-driven reduction and, inside the FCAFFN kernel, the cold second pass)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from common import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+PLANNED_H = [736, 368, 184, 544, 272, 136]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import fdn_hip
+    fdn_hip.lib()
+    from fdn_hip import ops as o
+    return o
+
+
+def dev(t):
+    return t.to("cuda:0").contiguous()
+
+
+def _rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def _rd(v):
+    return torch.where((v < 1e-10) & (v > -1e-10), torch.full_like(v, 1e-10), v)
+
+
+@pytest.mark.parametrize("H", PLANNED_H)
+@pytest.mark.parametrize("Wf", [641, 33, 7])
+def test_cols_fwd_matches_fft(ops, H, Wf):
+    z = _rnd(2, 3, H, Wf, 2, seed=H + Wf)
+    mag, ang = ops.fft_cols_fwd(dev(z), True, True, rd_before=False, fix_real=False)
+    ref = torch.fft.fft(torch.view_as_complex(z.double()), dim=2)
+    assert rel_rms(mag.cpu(), ref.abs()) < 2e-6
+    got = torch.polar(mag.cpu().double(), ang.cpu().double())
+    assert rel_rms(torch.view_as_real(got), torch.view_as_real(ref)) < 3e-6
+    only_abs, none = ops.fft_cols_fwd(dev(z), True, False, rd_before=False, fix_real=False)
+    assert none is None and torch.equal(only_abs, mag)
+
+
+def test_cols_fwd_fix_real_and_denormals(ops):
+    """fix_real forces Im = +0 at the four self-conjugate bins (angle +pi for negative real bins); rd_before replaces
+    (-1e-10, 1e-10) components by 1e-10 before abs / angle (FDN_arch.py:548-553)."""
+    H, W = 368, 64
+    x = -torch.ones(1, 1, H, W)                       # DC bin = -H*W: angle must be +pi, not -pi
+    z = ops.rfft_rows(dev(x))
+    mag, ang = ops.fft_cols_fwd(z, True, True, rd_before=False, fix_real=True)
+    assert abs(ang[0, 0, 0, 0].item() - math.pi) < 1e-6
+    zero = torch.zeros(1, 1, H, W // 2 + 1, 2)
+    mag, ang = ops.fft_cols_fwd(dev(zero), True, True, rd_before=True, fix_real=False)
+    assert torch.allclose(mag.cpu(), torch.full_like(mag.cpu(), 2 ** 0.5 * 1e-10), rtol=1e-6)
+    assert torch.allclose(ang.cpu(), torch.full_like(ang.cpu(), math.pi / 4), rtol=1e-6)
+
+
+@pytest.mark.parametrize("H", PLANNED_H)
+def test_cols_inv_polar_matches_ifft(ops, H):
+    Wf, Hin, Wfin = 41, H + 2, 45                    # leading (H, Wf) slice of wider planes, as fourier_fuse crops them
+    mag = _rnd(2, 2, Hin, Wfin, seed=H).abs() + 0.1
+    pha = (torch.rand(2, 2, Hin, Wfin, generator=torch.Generator().manual_seed(H + 1)) * 2 - 1) * math.pi
+    z = ops.fft_cols_inv_polar(dev(mag), dev(pha), H, Wf)
+    spec = torch.polar(mag[:, :, :H, :Wf].double(), pha[:, :, :H, :Wf].double())
+    ref = torch.fft.ifft(spec, dim=2) * H             # the column pass is unnormalised; irfft_rows carries the scale
+    assert rel_rms(z.cpu(), torch.view_as_real(ref)) < 3e-6
+
+
+def _fcaffn_ref(z, amp, pha, wxa, wxp):
+    """float64 restatement of FDN_arch.py:411-418 for the column pass (forward FFT over H, modulation, unnormalised inverse);
+    the phase is formed in float32 like the kernel does, so that large phases compare bin for bin."""
+    Z = torch.fft.fft(torch.view_as_complex(z.double()), dim=2)
+    Zr = torch.complex(_rd(Z.real.float()).double(), _rd(Z.imag.float()).double())
+    A = torch.einsum("ci,bihw->bchw", wxa.double(), amp.double())
+    ph = torch.einsum("ci,bihw->bchw", wxp, pha).double() if wxp.abs().max() < 100 else (wxp[:, 0].view(1, -1, 1, 1) * pha[:, :1]).double()
+    out = Zr * A * torch.polar(torch.ones_like(ph), -ph)
+    return torch.view_as_real(torch.fft.ifft(out, dim=2) * Z.shape[2])
+
+
+@pytest.mark.parametrize("H,C,Wf", [(736, 8, 73), (368, 16, 161), (184, 8, 161), (544, 8, 20), (272, 3, 9), (136, 16, 33)])
+def test_cols_fcaffn_matches_reference_math(ops, H, C, Wf):
+    B = 2
+    z = _rnd(B, C, H, Wf, 2, seed=H)
+    amp = _rnd(B, 3, H, Wf, seed=H + 1).abs()
+    pha = (torch.rand(B, 3, H, Wf, generator=torch.Generator().manual_seed(H + 2)) * 2 - 1) * math.pi
+    wxa, wxp = _rnd(C, 3, seed=H + 3), _rnd(C, 3, seed=H + 4)
+    got = ops.fft_cols_fcaffn(dev(z).clone(), dev(amp), dev(pha), dev(wxa), dev(wxp))
+    ref = _fcaffn_ref(z, amp, pha, wxa, wxp)
+    assert rel_rms(got.cpu(), ref) < 5e-6
+
+
+def test_cols_fcaffn_large_phases_take_the_full_range_path(ops):
+    """|phase| >= 8192 in some bins of some threads: the kernel's first pass flags it and the thread redoes its bins with the
+    full-range sin / cos.  wxp = (w, 0, 0) keeps the float32 phase a single exact product, so the reference sees the same angles."""
+    B, C, H, Wf = 1, 8, 736, 24
+    z = _rnd(B, C, H, Wf, 2, seed=5)
+    amp = _rnd(B, 3, H, Wf, seed=6).abs()
+    pha = (torch.rand(B, 3, H, Wf, generator=torch.Generator().manual_seed(7)) * 2 - 1) * math.pi
+    wxa = _rnd(C, 3, seed=8)
+    wxp = torch.zeros(C, 3)
+    wxp[:, 0] = torch.tensor([1.0, 3000.0, 2.6e3, 1e5, 4e9, -7e3, 2.0, 1e20])     # channels 0 and 6 stay on the fast path
+    got = ops.fft_cols_fcaffn(dev(z).clone(), dev(amp), dev(pha), dev(wxa), dev(wxp))
+    ref = _fcaffn_ref(z, amp, pha, wxa, wxp)
+    for ch in range(C):
+        assert rel_rms(got[:, ch].cpu(), ref[:, ch]) < 5e-6, ch
+
+
+def test_sincos_whole_float_range(ops):
+    g = torch.Generator().manual_seed(11)
+    mags = torch.cat([torch.rand(200000, generator=g) * 16000.0,                                   # both sides of the 8192 switch
+                      torch.exp(torch.rand(200000, generator=g) * (88.0 - 9.0) + 9.0),             # 8e3 .. 1.6e38, log-uniform
+                      torch.tensor([8191.9995, 8192.0, 8192.001, 3.4028235e38, 1e-30, 0.0, 2.0 ** 40, 2.0 ** 100])])
+    x = torch.cat([mags, -mags]).float()
+    sn, cs = ops.sincos(dev(x))
+    xd = x.double().numpy()
+    assert np.abs(sn.cpu().double().numpy() - np.sin(xd)).max() < 2e-7
+    assert np.abs(cs.cpu().double().numpy() - np.cos(xd)).max() < 2e-7
+    bad = torch.tensor([float("inf"), float("-inf"), float("nan")])
+    sn, cs = ops.sincos(dev(bad))
+    assert torch.isnan(sn).all() and torch.isnan(cs).all()

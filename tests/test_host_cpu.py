@@ -133,3 +133,39 @@ def test_tiling_origins_match_oracle_and_reject_cpu():
         tiling.split(torch.zeros(1, 3, 64, 64), 32, 32)
     with pytest.raises(fdn_hip.FdnHipError):
         tiling.tile_origins(64, 64, 128, 32)
+
+
+def test_sincos_large_argument_table():
+    """The large-argument reduction of fdn_sincos (csrc/common.hpp) restated with exact rationals on the committed table
+    (csrc/sincos_table.inc, made by tools/gen_sincos_table.py): x * 2/pi mod 4 = m * T[e] mod 4 for |x| = m * 2^e."""
+    import math
+    import os
+    import struct
+    from fractions import Fraction
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = []
+    for line in open(os.path.join(root, "fdn-tip2025_amd", "csrc", "sincos_table.inc")):
+        if line.startswith("{"):
+            hi, lo = line.strip().strip("{},").split(",")
+            rows.append((float.fromhex(hi.strip()), float.fromhex(lo.strip())))
+    assert len(rows) == 115
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([np.exp(rng.uniform(9.02, 88.7, 400)), [8192.0, 2.0 ** 40, 3.4028235e38]]).astype(np.float32)
+    for x in xs:
+        bits = struct.unpack("<I", struct.pack("<f", float(x)))[0]
+        eb, m = bits >> 23, (bits & 0x7FFFFF) | 0x800000
+        assert Fraction(m) * Fraction(2) ** (eb - 150) == Fraction(float(x))
+        fh, fl = rows[eb - 140]
+        exact = Fraction(m) * Fraction(fh)
+        p = float(exact)                                   # the rounded fp64 product
+        pe = float(exact - Fraction(p))                    # fma(m, fh, -p): exact
+        kq = round(p)                                      # (ties cannot occur within the tolerance below)
+        fr = (p - kq) + float(Fraction(m) * Fraction(fl) + Fraction(pe))
+        r, q = fr * (math.pi / 2), kq & 3
+        s, c = math.sin(r), math.cos(r)
+        sn = (s, c, -s, -c)[q]
+        cs = (c, -s, -c, s)[q]
+        assert abs(sn - math.sin(float(x))) < 1e-12 and abs(cs - math.cos(float(x))) < 1e-12, float(x)
