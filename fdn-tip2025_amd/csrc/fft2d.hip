@@ -845,13 +845,13 @@ __device__ __forceinline__ void bstore_f2(f2 v, __amdgpu_buffer_rsrc_t r, unsign
 }
 
 template <int R, int P, int MODE>
-__global__ __launch_bounds__(256, 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
-    constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = 256 + 8, NJ = R * NG;
+__global__ __launch_bounds__(256, 3) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
+    constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = 256 + 4, NJ = R * NG;
     static_assert(TC / CJ == NG, "8 column groups");
     __shared__ f2 Y[R * KS];
-    __shared__ f2 twl[P * R];                       // twl[n2 * R + k1] = W_H^{n2 k1}
+    __shared__ f2 twl[(P - 1) * R];                 // twl[(n2 - 1) * R + k1] = W_H^{n2 k1}, n2 >= 1  (3 workgroups per CU: 53.5 KB)
     const int tid = threadIdx.x, Wf = a.Wf;
-    for (int i = tid; i < P * R; i += 256) twl[i] = f2{twT[i].x, twT[i].y};
+    for (int i = tid; i < (P - 1) * R; i += 256) twl[i] = f2{twT[R + i].x, twT[R + i].y};
     // work order: every XCD walks a contiguous run of items ordered (batch, chunk of 8 channels, column tile, channel in chunk):
     // the tiles either side of a shared 128-byte line run within a few workgroups of each other on one L2, and the guidance
     // records of a tile (shared by all channels of a batch item) are re-read from memory once per chunk only
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(256, 2) void fft_cols_rp_kernel(ColArgs a, const fl
 #pragma unroll
                 for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = yb[N2 * TC + cc];
                 if constexpr (N2 > 0) {
-                    const f2 w = twl[N2 * R + k1];
+                    const f2 w = twl[(N2 - 1) * R + k1];
 #pragma unroll
                     for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = fftr::cmul(v[cc * P + N2], w);
                 }
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256, 2) void fft_cols_rp_kernel(ColArgs a, const fl
         sfor<0, P>([&](auto n) {
             constexpr int N2 = decltype(n)::value;
             if constexpr (N2 > 0) {
-                const f2 w = twl[N2 * R + k1];
+                const f2 w = twl[(N2 - 1) * R + k1];
 #pragma unroll
                 for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = fftr::cmulc(v[cc * P + N2], w);
             }
@@ -1184,6 +1184,269 @@ int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
                        : launch_cols_k<MODE, false, false>(a, p, planes, lds, stream);
 }
 
+// ------------------------------------------------------------------------------------------
+// Rows with a compile-time plan: half-length M = R1 * P with R1 = 20 (720p: W = 1280 / 640 / 320) or 30 (1080p: 1920 /
+// 960 / 480) and P = 32 / 16 / 8.  Same scheme as the planned columns: thread (n2, row) runs the R1-point DFT over n1 on
+// values loaded straight from memory, LDS transposes, thread (k1, row group) runs the P-point FFTs of its 32 / P rows, and the
+// r2c split (c2r merge) works on natural-order rows in LDS with coalesced stores (loads).  256 / P rows per workgroup, two
+// LDS round trips; the generic passes needed five (R = 5, 4, 4, 4, 2 for M = 640) plus a table copy per 3 rows.
+//   LDS: Y[row][k1][n2] with k1 stride P + 1 (conflict-free for both access directions), reused as Z[row][k]; then the
+//   transposed twiddles tw2[(n2 - 1) R1 + k1] = W_M^{n2 k1} and the split twiddles W_W^k, k <= M.
+// ------------------------------------------------------------------------------------------
+template <int R1, int P>
+struct RowPlan {
+    static constexpr int M = R1 * P, W = 2 * M, Wf = M + 1, RW = 256 / P, CJ = 32 / P, NG = 8, PS = P + 1, RS = R1 * PS, NJ = R1 * NG;
+    static constexpr int NTW = (P - 1) * R1 + Wf;
+    static constexpr size_t lds = ((size_t)RW * RS + NTW) * sizeof(float2);
+};
+
+template <int R1, int P>
+__global__ __launch_bounds__(256, 2) void rfft_rows_rp_kernel(const float* __restrict__ in, float2* __restrict__ out, long R,
+                                                              const float2* __restrict__ tab) {
+    typedef RowPlan<R1, P> L;
+    constexpr int M = L::M, W = L::W, Wf = L::Wf, RW = L::RW, CJ = L::CJ, PS = L::PS, RS = L::RS, NJ = L::NJ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2* Y = reinterpret_cast<f2*>(smem);
+    f2* tw2 = Y + RW * RS;
+    f2* tws = tw2 + (P - 1) * R1;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L::NTW; i += 256) tw2[i] = f2{tab[i].x, tab[i].y};
+    const long row0 = (long)blockIdx.x * RW;
+    const int nrow = (int)min((long)RW, R - row0);
+    {
+        const int n2 = tid & (P - 1), rw = tid / P;
+        const int rwc = rw < nrow ? rw : nrow - 1;                           // rows past the end shadow the last one
+        const __amdgpu_buffer_rsrc_t rin = cols_rsrc(in + row0 * W, (long)nrow * W * 4);
+        const unsigned voff = (unsigned)(rwc * W + 2 * n2) * 4u;
+        f2 u[R1];
+        sfor<0, R1>([&](auto n1) { u[decltype(n1)::value] = bload_f2(rin, voff, (unsigned)(decltype(n1)::value * P * 8)); });
+        fftr::dft_nat<R1, false>(u);
+        sfor<0, R1>([&](auto k1) { Y[rw * RS + decltype(k1)::value * PS + n2] = u[decltype(k1)::value]; });
+    }
+    __syncthreads();
+    const int jt = (tid + 64 * (int)(blockIdx.x & 3)) & 255;
+    const bool worker = jt < NJ;
+    const int rg = jt / R1, k1 = jt - rg * R1;
+    f2 v[32];
+    if (worker) {
+        const f2* yb = Y + rg * CJ * RS + k1 * PS;
+        sfor<0, P>([&](auto n) {
+            constexpr int N2 = decltype(n)::value;
+#pragma unroll
+            for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = yb[cc * RS + N2];
+            if constexpr (N2 > 0) {
+                const f2 w = tw2[(N2 - 1) * R1 + k1];
+#pragma unroll
+                for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = fftr::cmul(v[cc * P + N2], w);
+            }
+        });
+#pragma unroll
+        for (int cc = 0; cc < CJ; ++cc) fftr::dft_nat<P, false>(v + cc * P);
+    }
+    __syncthreads();                                                        // every Y cell has been read
+    if (worker) {
+        f2* zb = Y + rg * CJ * RS + k1;
+        sfor<0, P>([&](auto k2) {
+#pragma unroll
+            for (int cc = 0; cc < CJ; ++cc) zb[cc * RS + R1 * decltype(k2)::value] = v[cc * P + decltype(k2)::value];
+        });
+    }
+    __syncthreads();
+    // split: X[k] = E[k] + W_W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i (Z[k] - conj Z[M-k]) / 2
+    f2* out2 = reinterpret_cast<f2*>(out) + row0 * Wf;
+    const int live = nrow * Wf;
+    const float r_Wf = 1.0f / (float)Wf;
+#pragma unroll 4
+    for (int idx = tid; idx < live; idx += 256) {
+        const int s = fdiv(idx, r_Wf), k = idx - s * Wf;
+        const f2 zk = Y[s * RS + (k == M ? 0 : k)];
+        const f2 zc = Y[s * RS + (k == 0 ? 0 : M - k)];
+        const f2 e = 0.5f * f2{zk.x + zc.x, zk.y - zc.y};
+        const f2 d = 0.5f * f2{zk.x - zc.x, zk.y + zc.y};                   // (Z - conj Zc) / 2
+        const f2 o = fftr::mul_ni(d);
+        f2 x;
+        if (k == 0) x = f2{e.x + o.x, 0.0f};
+        else if (k == M) x = f2{e.x - o.x, 0.0f};
+        else x = e + fftr::cmul(o, tws[k]);
+        out2[idx] = x;
+    }
+}
+
+template <int R1, int P>
+__global__ __launch_bounds__(256, 2) void irfft_rows_rp_kernel(const float2* __restrict__ in, long in_ws, long in_plane_stride,
+                                                               float* __restrict__ out, int H, long R, float scale,
+                                                               const float* __restrict__ res, float alpha,
+                                                               const float2* __restrict__ tab) {
+    typedef RowPlan<R1, P> L;
+    constexpr int M = L::M, W = L::W, RW = L::RW, CJ = L::CJ, PS = L::PS, RS = L::RS, NJ = L::NJ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2* Y = reinterpret_cast<f2*>(smem);
+    f2* tw2 = Y + RW * RS;
+    f2* tws = tw2 + (P - 1) * R1;
+    __shared__ long rowoff[RW];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L::NTW; i += 256) tw2[i] = f2{tab[i].x, tab[i].y};
+    const long row0 = (long)blockIdx.x * RW;
+    const int nrow = (int)min((long)RW, R - row0);
+    if (tid < RW) {
+        const long row = row0 + min(tid, nrow - 1);
+        const long plane = row / H, h = row - plane * H;
+        rowoff[tid] = plane * in_plane_stride + h * in_ws;
+    }
+    __syncthreads();
+    {   // merge: Z[k] = E + i O,  E = (X[k] + conj X[M-k]) / 2,  O = (X[k] - conj X[M-k]) / 2 * W_W^{-k}
+        constexpr int UL = 5, TOT = RW * M;                           // TOT = 256 * R1, R1 = 20 | 30
+        static_assert(TOT % (256 * UL) == 0, "whole batches");
+        const f2* in2 = reinterpret_cast<const f2*>(in);
+        for (int base = tid; base < TOT; base += 256 * UL) {
+            f2 xks[UL], xcs[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int idx = base + 256 * u, s = idx / M, k = idx - s * M;
+                const f2* src = in2 + rowoff[s];
+                xks[u] = src[k];
+                xcs[u] = src[M - k];
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int idx = base + 256 * u, s = idx / M, k = idx - s * M;
+                f2 xk = xks[u], xc = xcs[u];
+                if (k == 0) { xk.y = 0.f; xc.y = 0.f; }                     // c2r ignores Im of DC and Nyquist
+                const f2 e = 0.5f * f2{xk.x + xc.x, xk.y - xc.y};
+                const f2 d = 0.5f * f2{xk.x - xc.x, xk.y + xc.y};
+                const f2 o = fftr::cmulc(d, tws[k]);                         // * W^{-k}
+                Y[s * RS + k] = e + fftr::mul_pi(o);
+            }
+        }
+    }
+    __syncthreads();
+    const int jt = (tid + 64 * (int)(blockIdx.x & 3)) & 255;
+    const bool worker = jt < NJ;
+    const int rg = jt / R1, k1 = jt - rg * R1;
+    f2 v[32];
+    if (worker) {
+        const f2* zb = Y + rg * CJ * RS + k1;
+        sfor<0, P>([&](auto k2) {
+#pragma unroll
+            for (int cc = 0; cc < CJ; ++cc) v[cc * P + decltype(k2)::value] = zb[cc * RS + R1 * decltype(k2)::value];
+        });
+#pragma unroll
+        for (int cc = 0; cc < CJ; ++cc) fftr::dft_nat<P, true>(v + cc * P);
+    }
+    __syncthreads();                                                        // every Z cell has been read
+    if (worker) {
+        f2* yb = Y + rg * CJ * RS + k1 * PS;
+        sfor<0, P>([&](auto n) {
+            constexpr int N2 = decltype(n)::value;
+            if constexpr (N2 > 0) {
+                const f2 w = tw2[(N2 - 1) * R1 + k1];
+#pragma unroll
+                for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = fftr::cmulc(v[cc * P + N2], w);
+            }
+#pragma unroll
+            for (int cc = 0; cc < CJ; ++cc) yb[cc * RS + N2] = v[cc * P + N2];
+        });
+    }
+    __syncthreads();
+    {
+        const int n2 = tid & (P - 1), rw = tid / P;
+        f2 u[R1];
+        sfor<0, R1>([&](auto k) { u[decltype(k)::value] = Y[rw * RS + decltype(k)::value * PS + n2]; });
+        fftr::dft_nat<R1, true>(u);
+        if (rw < nrow) {
+            const __amdgpu_buffer_rsrc_t ro = cols_rsrc(out + row0 * W, (long)nrow * W * 4);
+            const __amdgpu_buffer_rsrc_t rr = cols_rsrc(res ? res + row0 * W : out, res ? (long)nrow * W * 4 : 0);
+            const unsigned voff = (unsigned)(rw * W + 2 * n2) * 4u;
+            f2 r[R1];
+            if (res) sfor<0, R1>([&](auto n1) { r[decltype(n1)::value] = bload_f2(rr, voff, (unsigned)(decltype(n1)::value * P * 8)); });
+            sfor<0, R1>([&](auto n1) {
+                constexpr int N1 = decltype(n1)::value;
+                f2 x = u[N1] * scale;
+                if (res) x += alpha * r[N1];
+                bstore_f2(x, ro, voff, (unsigned)(N1 * P * 8));
+            });
+        }
+    }
+}
+
+// [ (P-1) * R1 transposed twiddles W_M^{n2 k1} | M + 1 split twiddles W_W^k ], exact on the axes
+const float2* get_table_rows_rp(int R1, int P) {
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int key = -(1 << 24) - (R1 * 1024 + P);
+    auto it = g_tables.find({devid, key});
+    if (it != g_tables.end()) return it->second;
+    const int M = R1 * P, W = 2 * M;
+    auto root = [](long t, long N) {
+        t %= N;
+        double c, s;
+        if ((4 * t) % N == 0) {
+            const int q = (int)((4 * t) / N);
+            c = (q == 0) ? 1.0 : (q == 2 ? -1.0 : 0.0);
+            s = (q == 1) ? 1.0 : (q == 3 ? -1.0 : 0.0);
+        } else {
+            const double ang = 2.0 * M_PI * (double)t / (double)N;
+            c = cos(ang); s = sin(ang);
+        }
+        float2 w = make_float2((float)c, (float)(-s) + 0.0f);
+        if (w.y == 0.0f) w.y = 0.0f;
+        if (w.x == 0.0f) w.x = 0.0f;
+        return w;
+    };
+    std::vector<float2> h;
+    for (int n2 = 1; n2 < P; ++n2)
+        for (int k1 = 0; k1 < R1; ++k1) h.push_back(root((long)n2 * k1, M));
+    for (int k = 0; k <= M; ++k) h.push_back(root(k, W));
+    float2* d = nullptr;
+    if (hipMalloc(&d, sizeof(float2) * h.size()) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    g_tables[{devid, key}] = d;
+    return d;
+}
+
+template <int R1, int P>
+int launch_rfft_rp(const float* in, float* out_c, long rows, fdn_stream_t stream) {
+    typedef RowPlan<R1, P> L;
+    const float2* tab = get_table_rows_rp(R1, P);
+    if (!tab) return FDN_ERR_LAUNCH;
+    if (int e = set_lds(rfft_rows_rp_kernel<R1, P>, L::lds)) return e;
+    hipLaunchKernelGGL((rfft_rows_rp_kernel<R1, P>), dim3(cdiv(rows, L::RW)), dim3(256), L::lds, static_cast<hipStream_t>(stream), in,
+                       reinterpret_cast<float2*>(out_c), rows, tab);
+    return fdn_launch_status();
+}
+
+template <int R1, int P>
+int launch_irfft_rp(const float* in_c, long in_row_bins, long in_plane_bins, float* out, long planes, int H, float scale,
+                    const float* res, float alpha, fdn_stream_t stream) {
+    typedef RowPlan<R1, P> L;
+    const float2* tab = get_table_rows_rp(R1, P);
+    if (!tab) return FDN_ERR_LAUNCH;
+    if (int e = set_lds(irfft_rows_rp_kernel<R1, P>, L::lds)) return e;
+    const long rows = planes * H;
+    hipLaunchKernelGGL((irfft_rows_rp_kernel<R1, P>), dim3(cdiv(rows, L::RW)), dim3(256), L::lds, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float2*>(in_c), in_row_bins, in_plane_bins, out, H, rows, scale, res, alpha, tab);
+    return fdn_launch_status();
+}
+
+// W -> (R1, P) of the planned row kernels; 0 = none
+bool rows_plan(int W, int* R1, int* P) {
+    for (int r : {20, 30})
+        for (int p : {32, 16, 8})
+            if (W == 2 * r * p) { *R1 = r; *P = p; return true; }
+    return false;
+}
+#define FDN_ROWS_DISPATCH(CALL)                                        \
+    switch (R1 * 64 + P) {                                             \
+        case 20 * 64 + 32: return CALL(20, 32);                        \
+        case 20 * 64 + 16: return CALL(20, 16);                        \
+        case 20 * 64 + 8: return CALL(20, 8);                          \
+        case 30 * 64 + 32: return CALL(30, 32);                        \
+        case 30 * 64 + 16: return CALL(30, 16);                        \
+        case 30 * 64 + 8: return CALL(30, 8);                          \
+        default: break;                                                \
+    }
+
 }  // namespace
 
 extern "C" int fdn_fft_prepare(int n) {
@@ -1214,6 +1477,14 @@ extern "C" int fdn_sincos_f32(const float* x, float* sn, float* cs, long n, fdn_
 
 extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t stream) {
     FDN_CHECK_ARG(in && out_c && rows > 0 && W >= 2 && W % 2 == 0);
+    {
+        int R1 = 0, P = 0;
+        if (rows_plan(W, &R1, &P) && (reinterpret_cast<uintptr_t>(in) & 7) == 0) {
+#define FDN_CALL(a, b) launch_rfft_rp<a, b>(in, out_c, rows, stream)
+            FDN_ROWS_DISPATCH(FDN_CALL)
+#undef FDN_CALL
+        }
+    }
     Plan p;
     if (!make_plan(W / 2, W, &p)) return FDN_ERR_UNSUPPORTED;
     Rader rd = {};
@@ -1237,6 +1508,14 @@ extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fd
 extern "C" int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane_bins, float* out, long planes, int H, int W,
                               float scale, const float* res, float alpha, fdn_stream_t stream) {
     FDN_CHECK_ARG(in_c && out && planes > 0 && H > 0 && W >= 2 && W % 2 == 0 && in_row_bins >= W / 2 + 1);
+    {
+        int R1 = 0, P = 0;
+        if (rows_plan(W, &R1, &P) && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res)) & 7) == 0) {
+#define FDN_CALL(a, b) launch_irfft_rp<a, b>(in_c, in_row_bins, in_plane_bins, out, planes, H, scale, res, alpha, stream)
+            FDN_ROWS_DISPATCH(FDN_CALL)
+#undef FDN_CALL
+        }
+    }
     Plan p;
     if (!make_plan(W / 2, W, &p)) return FDN_ERR_UNSUPPORTED;
     const int rpb = pick_rpb(W / 2);

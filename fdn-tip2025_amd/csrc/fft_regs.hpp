@@ -5,6 +5,7 @@
 //   dft_odd_c<R, INV>     R-point DFT of an odd R on (re, im) pairs, roots folded into the instruction stream
 //   fft_dif<N, INV>       radix-2 decimation in frequency: natural order in, bit-reversed order out
 //   fft_dit<N, INV>       radix-2 decimation in time: bit-reversed order in, natural order out
+//   dft_nat<N, INV>       any small N (2^a 3^b 5^c ...), natural order in and out, radix 4 where it divides
 //
 // A forward fft_dif followed by a pointwise operation and an inverse fft_dit therefore needs no permutation at all.
 // Values are packed (re, im) ext-vectors so adds / scalar multiplies become v_pk_* instructions.
@@ -141,6 +142,47 @@ __device__ __forceinline__ void dft_odd_c(f2* u) {
         u[R - O] = Pv - mul_pi(S);
     });
     u[0] = x0;
+}
+
+
+// N-point DFT of any small N, natural order in and out: Cooley-Tukey on the smallest prime factor, every twiddle a constant.
+constexpr int spf(int n) {
+    for (int f = 2; f * f <= n; ++f)
+        if (n % f == 0) return f;
+    return n;
+}
+
+template <int N, bool INV>
+__device__ __forceinline__ void dft_nat(f2* u) {
+    if constexpr (N == 2) {
+        const f2 a = u[0], b = u[1];
+        u[0] = a + b;
+        u[1] = a - b;
+    } else if constexpr (N == 4) {
+        const f2 a = u[0] + u[2], b = u[0] - u[2], c = u[1] + u[3], d = u[1] - u[3];
+        const f2 jd = INV ? mul_pi(d) : mul_ni(d);
+        u[0] = a + c;
+        u[1] = b + jd;
+        u[2] = a - c;
+        u[3] = b - jd;
+    } else if constexpr (N > 2 && spf(N) == N) {
+        dft_odd_c<N, INV>(u);
+    } else if constexpr (N > 4) {
+        constexpr int N1 = (N % 4 == 0) ? 4 : spf(N), N2 = N / N1;       // n = N2 n1 + n2,  k = k1 + N1 k2
+        f2 t[N];
+        sfor<0, N2>([&](auto n2) {
+            constexpr int Q = decltype(n2)::value;
+            f2 w[N1];
+            sfor<0, N1>([&](auto n1) { w[decltype(n1)::value] = u[N2 * decltype(n1)::value + Q]; });
+            dft_nat<N1, INV>(w);
+            sfor<0, N1>([&](auto k1) { t[decltype(k1)::value * N2 + Q] = mul_root<N, Q * decltype(k1)::value, INV>(w[decltype(k1)::value]); });
+        });
+        sfor<0, N1>([&](auto k1) {
+            constexpr int K = decltype(k1)::value;
+            dft_nat<N2, INV>(t + K * N2);
+            sfor<0, N2>([&](auto k2) { u[K + N1 * decltype(k2)::value] = t[K * N2 + decltype(k2)::value]; });
+        });
+    }
 }
 
 }  // namespace fftr

@@ -126,3 +126,40 @@ def test_sincos_whole_float_range(ops):
     bad = torch.tensor([float("inf"), float("-inf"), float("nan")])
     sn, cs = ops.sincos(dev(bad))
     assert torch.isnan(sn).all() and torch.isnan(cs).all()
+
+
+PLANNED_W = [1280, 640, 320, 1920, 960, 480]
+
+
+@pytest.mark.parametrize("W", PLANNED_W)
+@pytest.mark.parametrize("rows", [37, 64, 3])
+def test_rfft_rows_planned(ops, W, rows):
+    """Row r2c with a compile-time plan (half-length 20|30 x 32|16|8), incl. a last workgroup with fewer rows than it holds."""
+    x = _rnd(1, 1, rows, W, seed=W + rows)
+    z = ops.rfft_rows(dev(x))
+    ref = torch.view_as_real(torch.fft.rfft(x.double(), dim=-1))
+    assert rel_rms(z.cpu(), ref) < 2e-6
+    assert z[..., 0, 1].abs().max().item() == 0.0 and z[..., W // 2, 1].abs().max().item() == 0.0     # DC / Nyquist exactly real
+
+
+@pytest.mark.parametrize("W", PLANNED_W)
+def test_irfft_rows_planned(ops, W):
+    """Row c2r: plain, with the residual epilogue, and on the leading (H, W/2+1) slice of wider / taller spectra."""
+    H, Hin, Wf = 21, 23, W // 2 + 1
+    Wfin = Wf + 3
+    z = _rnd(2, 2, Hin, Wfin, 2, seed=W)
+    res = _rnd(2, 2, H, W, seed=W + 1)
+    scale = 2.0 / (H * W)
+    zc = torch.view_as_complex(z.double())[:, :, :H, :Wf]
+    ref = torch.fft.irfft(zc, n=W, dim=-1) * (W / 2) * scale
+    got = ops.irfft_rows(dev(z), H, W, scale)
+    assert rel_rms(got.cpu(), ref) < 3e-6
+    got = ops.irfft_rows(dev(z), H, W, scale, res=dev(res), alpha=0.75)
+    assert rel_rms(got.cpu(), ref + 0.75 * res.double()) < 3e-6
+
+
+def test_rows_round_trip_at_bench_shape(ops):
+    x = _rnd(1, 4, 736, 1280, seed=3)
+    z = ops.rfft_rows(dev(x))
+    back = ops.irfft_rows(z, 736, 1280, 2.0 / 1280)
+    assert rel_rms(back.cpu(), x) < 2e-6
