@@ -1294,28 +1294,36 @@ __global__ __launch_bounds__(256, 2) void irfft_rows_rp_kernel(const float2* __r
         rowoff[tid] = plane * in_plane_stride + h * in_ws;
     }
     __syncthreads();
-    {   // merge: Z[k] = E + i O,  E = (X[k] + conj X[M-k]) / 2,  O = (X[k] - conj X[M-k]) / 2 * W_W^{-k}
-        constexpr int UL = 5, TOT = RW * M;                           // TOT = 256 * R1, R1 = 20 | 30
-        static_assert(TOT % (256 * UL) == 0, "whole batches");
+    {   // merge on pairs (k, M - k), every bin loaded once:  E = (X[k] + conj X[M-k]) / 2,  O = (X[k] - conj X[M-k]) / 2 * W_W^{-k},
+        // Z[k] = E + i O,  Z[M-k] = conj(E - i O)  (W_W^{M-k} = -conj W_W^k): one twiddle product per pair
+        constexpr int UL = 4, NP = M / 2 + 1, TOT = RW * NP;
         const f2* in2 = reinterpret_cast<const f2*>(in);
+        const float r_NP = 1.0f / (float)NP;
         for (int base = tid; base < TOT; base += 256 * UL) {
             f2 xks[UL], xcs[UL];
 #pragma unroll
             for (int u = 0; u < UL; ++u) {
-                const int idx = base + 256 * u, s = idx / M, k = idx - s * M;
+                const int idx = min(base + 256 * u, TOT - 1), s = fdiv(idx, r_NP), k = idx - s * NP;
                 const f2* src = in2 + rowoff[s];
                 xks[u] = src[k];
                 xcs[u] = src[M - k];
             }
 #pragma unroll
             for (int u = 0; u < UL; ++u) {
-                const int idx = base + 256 * u, s = idx / M, k = idx - s * M;
+                const int idx = base + 256 * u;
+                if (idx >= TOT) continue;
+                const int s = fdiv(idx, r_NP), k = idx - s * NP;
                 f2 xk = xks[u], xc = xcs[u];
                 if (k == 0) { xk.y = 0.f; xc.y = 0.f; }                     // c2r ignores Im of DC and Nyquist
                 const f2 e = 0.5f * f2{xk.x + xc.x, xk.y - xc.y};
                 const f2 d = 0.5f * f2{xk.x - xc.x, xk.y + xc.y};
-                const f2 o = fftr::cmulc(d, tws[k]);                         // * W^{-k}
-                Y[s * RS + k] = e + fftr::mul_pi(o);
+                const f2 io = fftr::mul_pi(fftr::cmulc(d, tws[k]));           // i * O
+                f2* row = Y + s * RS;
+                row[k] = e + io;
+                if (k != 0) {                                                // (2k = M: the same value twice)
+                    const f2 c = e - io;
+                    row[M - k] = f2{c.x, -c.y};
+                }
             }
         }
     }
