@@ -845,7 +845,7 @@ __device__ __forceinline__ void bstore_f2(f2 v, __amdgpu_buffer_rsrc_t r, unsign
 }
 
 template <int R, int P, int MODE>
-__global__ __launch_bounds__(256, 3) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
+__global__ __launch_bounds__(256, 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
     constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = 256 + 4, NJ = R * NG;
     static_assert(TC / CJ == NG, "8 column groups");
     __shared__ f2 Y[R * KS];
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256, 3) void fft_cols_rp_kernel(ColArgs a, const fl
         binq[cc] = (unsigned)(k1 * Wf + (liveq[cc] ? col0 + cg * CJ + cc : Wf - 1));
     }
     const unsigned kstep = (unsigned)(R * Wf);      // bins between k2 and k2 + 1
-    constexpr int NB = 8, BS = 32 / NB;             // guidance records in batches of 4, one batch in flight ahead of the arithmetic
+    constexpr int NB = 4, BS = 32 / NB;             // guidance records in batches of 8, one batch in flight ahead of the arithmetic
     fdn_u32x4 g0[2][BS];
     fdn_u32x2 g1[2][BS];
     __amdgpu_buffer_rsrc_t rg = rz;
