@@ -157,11 +157,15 @@ class FCAFFN(nn.Module):
         z = ops.rfft_rows(xn)
         ops.fft_cols_fcaffn(z, x_high, xp2, _w(self.conv1_xa.weight), _w(self.conv1_xp.weight))
         xi = ops.irfft_rows(z, h, w, 2.0 / (h * w))
-        stats = ops.chan_stats(xi)
-        mul, add = ops.img_mod_maps(x_img, _w(self.conv1_mul.weight), _w(self.conv3_mul.weight),
-                                    _w(self.conv1_add.weight), _w(self.conv3_add.weight))
         gam, bet = self.norm.params()
-        t = ops.conv1x1(xi, _w(self.project_in.weight), ln_muladd=(stats, gam, bet, xn), muladd=(mul, add))
+        if xi.shape[1] in ops.FCAFFN_IN_C and w % 2 == 0:
+            t = ops.fcaffn_in(xi, xn, x_img, _w(self.project_in.weight), gam, bet, _w(self.conv1_mul.weight),
+                              _w(self.conv3_mul.weight), _w(self.conv1_add.weight), _w(self.conv3_add.weight))
+        else:
+            stats = ops.chan_stats(xi)
+            mul, add = ops.img_mod_maps(x_img, _w(self.conv1_mul.weight), _w(self.conv3_mul.weight),
+                                        _w(self.conv1_add.weight), _w(self.conv3_add.weight))
+            t = ops.conv1x1(xi, _w(self.project_in.weight), ln_muladd=(stats, gam, bet, xn), muladd=(mul, add))
         return ops.ffn_tail(t, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None)
 
     def forward(self, x, x_high, xp2, x_img=None):

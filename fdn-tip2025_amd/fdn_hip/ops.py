@@ -305,6 +305,20 @@ def img_mod_maps(img, w1_mul, w3_mul, w1_add, w3_add):
     return mul, add
 
 
+FCAFFN_IN_C = (32, 64)     # widths fdn_fcaffn_in has a form for
+
+
+def fcaffn_in(xi, x1, img, w, gamma, beta, w1_mul, w3_mul, w1_add, w3_add):
+    """project_in(norm(xi) * x1 + x1) * conv3_mul(conv1_mul(img)) + conv3_add(conv1_add(img)) in one launch (FDN_arch.py:419-423);
+    C in FCAFFN_IN_C, W even."""
+    B, C, H, W = xi.shape
+    out = torch.empty_like(xi)
+    check(lib().fdn_fcaffn_in(_flat(xi, "xi"), _flat(x1, "x1"), _flat(img, "img"), _flat(w, "w"), _flat(gamma, "gamma"),
+                              _flat(beta, "beta"), _flat(w1_mul, "w1_mul"), _flat(w3_mul, "w3_mul"), _flat(w1_add, "w1_add"),
+                              _flat(w3_add, "w3_add"), _flat(out, "out"), B, C, H, W, stream()), "fdn_fcaffn_in")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # full-image FFT pipeline
 # ---------------------------------------------------------------------------------------------

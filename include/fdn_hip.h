@@ -144,6 +144,16 @@ int fdn_ffn_tail(const void* y, const float* dw_w, const float* w, const float* 
 /* Plain depthwise 3x3 (zero pad 1), optional activation.  x,out [B][C][H][W], w [C][9]. */
 int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, int C, int H, int W, int act, fdn_stream_t stream);
 
+/* FCAFFN between the inverse FFT and the gated tail in one launch (FDN_arch.py:419-423):
+ *   out = project_in( norm(xi) * x1 + x1 ) * conv3_mul(conv1_mul(img)) + conv3_add(conv1_add(img))
+ * replaces fdn_chan_stats(xi) -> fdn_img_mod_maps(img) -> fdn_conv1x1(FDN_PRO_LN_MULADD, FDN_EPI_MULADD): the LayerNorm statistics
+ * come from the activation strip in registers, the two maps are MFMA chains on the image patch (never written to memory).
+ * xi, x1, out [B][C][H][W]; img [B][3][H][W]; w [C][C]; gamma, beta [C]; w1_* [C][3]; w3_* [C][9] (all convs without bias).
+ * C = 32 or 64, W even, tensors 8-byte aligned; anything else returns FDN_ERR_UNSUPPORTED (use the three calls above). */
+int fdn_fcaffn_in(const float* xi, const float* x1, const float* img, const float* w, const float* gamma, const float* beta,
+                  const float* w1_mul, const float* w3_mul, const float* w1_add, const float* w3_add, float* out, int B, int C,
+                  int H, int W, fdn_stream_t stream);
+
 /* FCAFFN spatial modulation maps (FDN_arch.py:423): mul = conv3_mul(conv1_mul(img)),
  * add = conv3_add(conv1_add(img)).  img [B][3][H][W]; w1_* [C][3]; w3_* [C][9]; outs [B][C][H][W]. */
 int fdn_img_mod_maps(const float* img, const float* w1_mul, const float* w3_mul, const float* w1_add,

@@ -96,3 +96,33 @@ def test_forward_streams_cold_start(A):
     ref = forward_streams(net2, lp2, x, 1)
     torch.cuda.synchronize()
     assert torch.equal(cold, ref)
+
+
+@pytest.mark.parametrize("C,H,W,B", [(32, 16, 40, 2), (32, 33, 66, 1), (64, 24, 24, 2), (64, 7, 130, 1), (32, 368, 640, 1)])
+def test_fcaffn_in_equals_unfused(A, C, H, W, B):
+    """fdn_fcaffn_in (statistics from the register strip, modulation maps as MFMA chains on the image patch) against
+    fdn_chan_stats -> fdn_img_mod_maps -> fdn_conv1x1(LN*x1+x1 prologue, *mul+add epilogue) on the same inputs.  The maps
+    use folded weights (w3 * w1 rounded once), so the two differ by rounding, not bit for bit."""
+    from fdn_hip import ops
+    xi, x1 = dev(_rnd(B, C, H, W, seed=1) * 1.3 + 0.2), dev(_rnd(B, C, H, W, seed=2))
+    img = dev(torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3)))
+    w = dev(_rnd(C, C, seed=4) / C ** 0.5)
+    g, b_ = dev(_rnd(C, seed=5) * 0.2 + 1.0), dev(_rnd(C, seed=6) * 0.1)
+    w1m, w3m = dev(_rnd(C, 3, seed=7)), dev(_rnd(C, 9, seed=8) / 3)
+    w1a, w3a = dev(_rnd(C, 3, seed=9)), dev(_rnd(C, 9, seed=10) / 3)
+    mul, add = ops.img_mod_maps(img, w1m, w3m, w1a, w3a)
+    ref = ops.conv1x1(xi, w, ln_muladd=(ops.chan_stats(xi), g, b_, x1), muladd=(mul, add))
+    got = ops.fcaffn_in(xi, x1, img, w, g, b_, w1m, w3m, w1a, w3a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 4e-6
+    assert rel_rms(got.cpu(), ref.cpu()) < 5e-7
+    # and against plain float64 math (FDN_arch.py:419-423)
+    xd, x1d = xi.double().cpu(), x1.double().cpu()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, keepdim=True, unbiased=False)
+    u = ((xd - mu) / torch.sqrt(var + 1e-5) * g.double().cpu().view(1, -1, 1, 1) + b_.double().cpu().view(1, -1, 1, 1)) * x1d + x1d
+    t = torch.einsum("nk,bkhw->bnhw", w.double().cpu(), u)
+    F = torch.nn.functional
+    m64 = F.conv2d(F.conv2d(img.double().cpu(), w1m.double().cpu().view(C, 3, 1, 1)), w3m.double().cpu().view(C, 1, 3, 3), padding=1, groups=C)
+    a64 = F.conv2d(F.conv2d(img.double().cpu(), w1a.double().cpu().view(C, 3, 1, 1)), w3a.double().cpu().view(C, 1, 3, 3), padding=1, groups=C)
+    assert rel_rms(got.cpu(), t * m64 + a64) < 2e-6
