@@ -8,6 +8,7 @@
 // Weights are streamed through LDS in 32-deep k' chunks (double buffered, one barrier per chunk),
 // re-gathered from the [Cout][Cin][3][3] checkpoint layout on the fly.
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -30,6 +31,7 @@ struct C3Args {
     int B, Cin, H, W, Cout;
     int act, res_before_act; float post_add;
     int tiles_per_img, total_tiles;
+    int n0, CoutT;             // tiled kernel: first output channel of this launch / output channels of the tensor (plane strides)
 };
 
 template <int MT, int NW>
@@ -163,6 +165,158 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_kernel(C3Arg
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled form for Cin % 8 == 0 and Cout = 32 / 64 (the Downsample / Upsample body convs, 64 -> 32 at level 1 and
+// 128 -> 64 at level 2: 278 GFLOP each).  The flat-pixel kernel above loads every input value nine times from global memory
+// (once per tap, 5-6x the algorithmic HBM bytes once the in-flight tiles outgrow L2: profiles/r02_c_summary.txt); here a
+// workgroup owns an 8 x 32 output tile, stages the 10 x 34 halo tile of 8 input channels in LDS (zero-filled outside the
+// image, double buffered) and every MFMA B operand is an LDS read at a compile-time offset: (tap, channel pair) k-steps,
+// 36 per chunk.  A wave computes two rows (two 32-pixel strips) x all output channels, so each A operand read from LDS feeds
+// two MFMAs.  The weight rows of a chunk (72 x Cout, gathered from the checkpoint layout: 72 consecutive floats per output
+// channel) stream through the second half of the double buffer; one barrier per chunk of 144 x Cout/32 MFMAs per wave.
+// ------------------------------------------------------------------------------------------------
+constexpr int TH = 8, TW = 32, CK = 8, HR = TH + 2, HC = TW + 2;
+constexpr int PL = 352;                        // plane stride of the staged tile (340 used): = 32 mod 64, the two k of a step hit disjoint banks
+constexpr int KST = 9 * CK / 2;                // k-steps per chunk
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void conv3x3_tiled_kernel(C3Args a, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int N = MT * 32, WS = N + 1;
+    constexpr int XB = CK * PL, WB = 9 * CK * WS;              // floats per buffer
+    constexpr int XE = (CK * HR * HC + 255) / 256;             // staged input elements per thread (11)
+    constexpr int WE = (9 * CK * N + 255) / 256;               // staged weight elements per thread
+    float* Xl = smem;                           // [2][CK][PL]
+    float* Wl = smem + 2 * XB;                  // [2][72][WS]
+    const int Cin = a.Cin, H = a.H, W = a.W;
+    const unsigned P = (unsigned)H * W, P4 = P * 4u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+    const int nchunk = Cin / CK;
+    int b, y0, x0;
+    {
+        const unsigned T = (unsigned)(tiles_x * tiles_y) * a.B;
+        const unsigned S = xcd_contiguous(blockIdx.x, T);          // neighbouring tiles (shared halo rows / lines) on one XCD
+        const unsigned per = (unsigned)(tiles_x * tiles_y);
+        b = (int)(S / per);
+        const unsigned t = S - (unsigned)b * per;
+        const int ty = (int)(t / (unsigned)tiles_x);
+        y0 = ty * TH;
+        x0 = (int)(t - (unsigned)ty * tiles_x) * TW;
+    }
+    // staging plan of this thread: the same positions for every chunk, only the channel base moves
+    unsigned xg[XE];                            // global byte offset inside the 8-channel slab (0x80000000 = outside the image: reads 0)
+    int xl[XE];                                 // LDS float offset, -1 = no element
+#pragma unroll
+    for (int i = 0; i < XE; ++i) {
+        const int e = tid + 256 * i;
+        const int ci = e / (HR * HC), q = e - ci * (HR * HC), r = q / HC, c = q - r * HC;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        const bool in = e < CK * HR * HC, ok = in && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xg[i] = ok ? ((unsigned)ci * P + (unsigned)(gy * W + gx)) * 4u : 0x80000000u;
+        xl[i] = in ? ci * PL + r * HC + c : -1;
+    }
+    const rsrc_t rx = mk_rsrc(a.x + (long)b * Cin * P, (unsigned)Cin * P4);
+    float xr[XE], wr[WE];
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XE; ++i) xr[i] = bload(rx, xg[i], (unsigned)(c * CK) * P4);
+#pragma unroll
+        for (int i = 0; i < WE; ++i) {
+            const int e = tid + 256 * i, n = e / (9 * CK), q = e - n * (9 * CK);      // 72 consecutive floats per output channel
+            wr[i] = (e < 9 * CK * N) ? a.w[((long)(a.n0 + n) * Cin + c * CK) * 9 + q] : 0.f;
+        }
+    };
+    auto stash = [&](int buf) __attribute__((always_inline)) {
+        float* xd = Xl + buf * XB;
+#pragma unroll
+        for (int i = 0; i < XE; ++i)
+            if (xl[i] >= 0) xd[xl[i]] = xr[i];
+        float* wd = Wl + buf * WB;
+#pragma unroll
+        for (int i = 0; i < WE; ++i) {
+            const int e = tid + 256 * i, n = e / (9 * CK), q = e - n * (9 * CK), ci = q / 9, tap = q - ci * 9;
+            if (e < 9 * CK * N) wd[(tap * CK + ci) * WS + n] = wr[i];                 // row k' = tap * 8 + ci
+        }
+    };
+    f32x16 acc[2][MT];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[st][m][r] = 0.f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int row0 = 2 * wave;                  // this wave's two output rows of the tile
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        if (more) fetch(c + 1);
+        const float* xb = Xl + (c & 1) * XB + kh * PL + row0 * HC + ln;
+        const float* wb = Wl + (c & 1) * WB + kh * WS + ln;
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            const int tap = s / (CK / 2), cp = s - tap * (CK / 2), dy = tap / 3, dx = tap - dy * 3;      // compile-time after unrolling
+            const float b0 = xb[(2 * cp) * PL + dy * HC + dx];
+            const float b1 = xb[(2 * cp) * PL + (dy + 1) * HC + dx];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float av = wb[(2 * s) * WS + m * 32];
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1][m], 0, 0, 0);
+            }
+        }
+        if (more) stash((c + 1) & 1);
+        __syncthreads();
+    }
+    // epilogue: rows y0 + row0 + {0, 1}, columns x0 + ln; the activation kind is resolved once, not per value
+    const unsigned nb4 = (unsigned)N * P4;
+    const long obase = ((long)b * a.CoutT + a.n0) * P;
+    const rsrc_t ro = mk_rsrc(a.out + obase, nb4);
+    const rsrc_t rr = mk_rsrc(a.res ? a.res + obase : a.out, a.res ? nb4 : 0u);
+    auto epilogue = [&](auto has_act) __attribute__((always_inline)) {
+        const int act_ = decltype(has_act)::value ? a.act : (int)FDN_ACT_NONE;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int gy = y0 + row0 + st, gx = x0 + ln;
+            const unsigned voff = (gy < H && gx < W) ? (4u * kh * P + (unsigned)(gy * W + gx)) * 4u : 0x80000000u;     // outside: dropped / 0
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float rv[16];
+                if (a.res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = bload(rr, voff, (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * P4);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                    float v = acc[st][m][r];
+                    if (a.bias) v += a.bias[a.n0 + nrow + 4 * kh];
+                    if (a.res && a.res_before_act) v += rv[r];
+                    v = apply_act(v, act_);
+                    if (a.res && !a.res_before_act) v += rv[r];
+                    bstore(v + a.post_add, ro, voff, (unsigned)nrow * P4);
+                }
+            }
+        }
+    };
+    if (a.act == FDN_ACT_NONE) epilogue(std::false_type{}); else epilogue(std::true_type{});
+}
+
+template <int MT>
+int launch_tiled(const C3Args& a, hipStream_t s) {
+    constexpr int N = MT * 32;
+    const size_t lds = (2UL * CK * PL + 2UL * 9 * CK * (N + 1)) * sizeof(float);
+    auto kern = conv3x3_tiled_kernel<MT>;
+    if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return FDN_ERR_LAUNCH;
+    const int tx = cdiv(a.W, TW), ty = cdiv(a.H, TH);
+    const long total = (long)tx * ty * a.B;
+    if (total > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, s, a, tx, ty);
+    return fdn_launch_status();
+}
+
 template <int MT, int NW>
 int launch(C3Args a, hipStream_t s) {
     const size_t lds = 2UL * KC * (MT * 32 + 1) * sizeof(float);
@@ -194,6 +348,13 @@ int fdn_conv3x3_mfma(const float* x, const float* w, const float* bias, const fl
     a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout;
     a.act = act; a.res_before_act = res_before_act; a.post_add = post_add;
     a.tiles_per_img = a.total_tiles = 0;
+    a.n0 = 0; a.CoutT = Cout;
+    if (Cin % CK == 0 && Cin >= 2 * CK && (Cout == 32 || Cout % 64 == 0)) {
+        if (Cout == 32) return launch_tiled<1>(a, s);
+        for (a.n0 = 0; a.n0 < Cout; a.n0 += 64)            // wider outputs: 64 channels per launch (four accumulator tiles x two strips spill)
+            if (int e = launch_tiled<2>(a, s)) return e;
+        return FDN_OK;
+    }
     const int tiles = (Cout + 31) / 32;
     if (tiles == 1) return launch<1, 4>(a, s);
     if (tiles == 2) return launch<2, 4>(a, s);

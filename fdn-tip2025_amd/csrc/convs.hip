@@ -318,6 +318,10 @@ extern "C" int fdn_conv2d(const float* x, const float* w, const float* bias, con
         // up to 64 output channels (64->32 @L1 5.5 vs 8.4 ms, 12->12 0.47 vs 2.0 ms); wider ones (64->128,
         // 128->64, whose weight slice does not fit LDS either) stay on MFMA
         int rc = FDN_ERR_UNSUPPORTED;
+        if (stride == 1 && Cin % 8 == 0 && Cin >= 16 && (Cout == 32 || Cout % 64 == 0)) {          // LDS-tiled MFMA form
+            rc = fdn_conv3x3_mfma(x, w, bias, res, out, B, Cin, H, W, Cout, act, res_before_act, post_add, s);
+            if (rc != FDN_ERR_UNSUPPORTED) return rc;
+        }
         if (stride == 2) rc = Cout <= 8 ? launch_conv3x3_direct<2, 8>(a, s) : launch_conv3x3_direct<2, 16>(a, s);
         else if (Cout <= 4) rc = launch_conv3x3_direct<1, 4>(a, s);
         else if (Cout <= 8) rc = launch_conv3x3_direct<1, 8>(a, s);

@@ -323,6 +323,28 @@ def test_conv3x3_paths(A, Cin, Cout, H, W, stride):
     assert rel_rms(ops.conv2d(dev(x), dev(w), dev(b), pad=1, stride=stride).cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("Cin,Cout,H,W,act,res_before", [(16, 32, 8, 32, 0, False), (64, 32, 37, 70, 2, True), (128, 64, 19, 33, 0, False),
+                                                          (24, 64, 5, 100, 2, False), (32, 64, 64, 64, 0, True), (64, 128, 9, 40, 1, True)])
+def test_conv3x3_tiled_options(A, Cin, Cout, H, W, act, res_before):
+    """LDS-tiled MFMA 3x3 (Cin % 8 == 0, Cout 32 / 64): partial tiles on both axes, bias, activation, residual before / after it."""
+    from fdn_hip import ops
+    x, w, b = _rnd(2, Cin, H, W, seed=1), _rnd(Cout, Cin, 3, 3, seed=2) / (3 * Cin ** 0.5), _rnd(Cout, seed=3)
+    res = _rnd(2, Cout, H, W, seed=4)
+    y = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res_before:
+        y = y + res.double()
+    if act == 2:
+        y = torch.relu(y)
+    elif act == 1:
+        y = torch.nn.functional.leaky_relu(y, 0.1)
+    if not res_before:
+        y = y + res.double()
+    got = ops.conv2d(dev(x), dev(w), dev(b), pad=1, act=act, res=dev(res), res_before_act=res_before)
+    assert rel_rms(got.cpu(), y) < 2e-6
+    plain = ops.conv2d(dev(x), dev(w), None, pad=1)
+    assert rel_rms(plain.cpu(), torch.nn.functional.conv2d(x.double(), w.double(), padding=1)) < 2e-6
+
+
 @pytest.mark.parametrize("Cin,Cout,H,W", [(24, 12, 9, 13), (48, 24, 8, 16), (6, 5, 7, 9)])
 def test_conv_transpose4x4s2(A, Cin, Cout, H, W):
     from fdn_hip import ops
