@@ -1453,6 +1453,9 @@ int launch_pro(const fdn_conv1x1_desc& d, hipStream_t s) {
 
 }  // namespace
 
+// gemm_tile.hip: LDS-tiled kernel for the deep N = 128 shapes; FDN_ERR_UNSUPPORTED = not one of them
+int fdn_gemm_tile(const fdn_conv1x1_desc& d, hipStream_t s);
+
 extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
     FDN_CHECK_ARG(dp != nullptr);
     fdn_conv1x1_desc d = *dp;
@@ -1509,6 +1512,10 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
             }
         }
         return FDN_ERR_UNSUPPORTED;
+    }
+    {
+        const int rc = fdn_gemm_tile(d, s);             // 459 -> 128 (LN3 * v_value), 345 -> 128, 128 -> 128 at level 3
+        if (rc != FDN_ERR_UNSUPPORTED) return rc;
     }
     // K = 64 with a weight matrix too big to sit in LDS three times per CU (level-2 to_hidden, 64 -> 304): stream the weights too
     if (d.K > KC && d.K <= 2 * KC && d.N >= 256 && !d.stats_out && d.kseg[1] == 0 && d.epi == FDN_EPI_NONE &&

@@ -237,7 +237,8 @@ def _rnd(*s, seed):
 
 @pytest.mark.parametrize("K,N,H,W,pro", [(32, 152, 24, 40, "ln"), (64, 304, 16, 24, "ln"), (128, 612, 8, 24, "ln"),
                                         (96, 345, 8, 16, "none"), (86, 32, 46, 21, "none"), (459, 128, 8, 16, "ln3"),
-                                        (114, 32, 24, 40, "ln3"), (32, 32, 16, 24, "muladd")])
+                                        (114, 32, 24, 40, "ln3"), (32, 32, 16, 24, "muladd"), (300, 128, 9, 21, "ln3"),
+                                        (200, 100, 9, 21, "none"), (345, 128, 23, 40, "none")])
 def test_conv1x1_variants(A, K, N, H, W, pro):
     """Every GEMM kernel variant (small-K resident / streaming, generic resident / streaming, prologues,
     epilogues, fused statistics) against fp64."""
