@@ -151,16 +151,17 @@ class FCAFFN(nn.Module):
         self.norm = LayerNorm(hidden)
         self.dwconv = nn.Conv2d(hidden, hidden * 2, kernel_size=3, padding=1, groups=hidden, bias=bias)
 
-    def fused(self, xn, x_high, xp2, x_img, res=None):
-        """xn: the block input (already norm3-normalised), kept as x1 (FDN_arch.py:410)."""
+    def fused(self, xn, x_high, xp2, x_img, res=None, ln=None):
+        """xn: the block input (already norm3-normalised), kept as x1 (FDN_arch.py:410).  ln = (stats, gamma, beta): xn is the
+        UN-normalised input and norm3 is applied on load by the row FFT and by fdn_fcaffn_in (no normalised copy)."""
         _, _, h, w = xn.shape
-        z = ops.rfft_rows(xn)
+        z = ops.rfft_rows_ln(xn, *ln) if ln is not None else ops.rfft_rows(xn)
         ops.fft_cols_fcaffn(z, x_high, xp2, _w(self.conv1_xa.weight), _w(self.conv1_xp.weight))
         xi = ops.irfft_rows(z, h, w, 2.0 / (h * w))
         gam, bet = self.norm.params()
         if xi.shape[1] in ops.FCAFFN_IN_C and w % 2 == 0:
             t = ops.fcaffn_in(xi, xn, x_img, _w(self.project_in.weight), gam, bet, _w(self.conv1_mul.weight),
-                              _w(self.conv3_mul.weight), _w(self.conv1_add.weight), _w(self.conv3_add.weight))
+                              _w(self.conv3_mul.weight), _w(self.conv1_add.weight), _w(self.conv3_add.weight), x1_ln=ln)
         else:
             stats = ops.chan_stats(xi)
             mul, add = ops.img_mod_maps(x_img, _w(self.conv1_mul.weight), _w(self.conv3_mul.weight),
@@ -195,7 +196,10 @@ class TransformerBlock(nn.Module):
             x = self.attn.fused(x, ln=(ops.stats_of(x),) + self.norm1.params(), res=x)
         x = self.ffn.fused(x, ln=(ops.stats_of(x),) + self.norm2.params(), res=x)
         if self.use_light:
-            x = self.ffn2.fused(self.norm3(x), x_high, x_p, x_img, res=x)
+            if x.shape[1] in ops.FCAFFN_IN_C and x.shape[3] in ops.ROWS_PLANNED_W:      # norm3 on load: no normalised copy of x
+                x = self.ffn2.fused(x, x_high, x_p, x_img, res=x, ln=(ops.stats_of(x),) + self.norm3.params())
+            else:
+                x = self.ffn2.fused(self.norm3(x), x_high, x_p, x_img, res=x)
         return x, x_high, x_p, x_img
 
 

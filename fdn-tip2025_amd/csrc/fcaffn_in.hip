@@ -47,6 +47,7 @@ __device__ __forceinline__ void bstorev(typename VecT<VEC>::type f, rsrc_t r, un
 
 struct Args {
     const float *xi, *x1, *img, *w, *gamma, *beta, *w1m, *w3m, *w1a, *w3a;
+    const float *stats1, *gamma1, *beta1;     // optional: x1 is norm(x1) with these per-pixel statistics [B][2][H*W] and affine parameters
     float* out;
     int B, C, H, W;
     int tiles_per_img, total_tiles;
@@ -66,8 +67,14 @@ __global__ __launch_bounds__(256, 2) void fcaffn_in_kernel(Args a) {
     float* Wl = tb + C;                          // [C][NS]   project_in, transposed
     float* Wm = Wl + C * NS;                     // [30][NS]  folded conv3_mul * conv1_mul, row j = c * 10 + tap
     float* Wa = Wm + 2 * MS * NS;                // [30][NS]  the same for add
+    float* tg1 = Wa + 2 * MS * NS;               // gamma1[C], beta1[C] (x1 LayerNorm on load)
+    float* tb1 = tg1 + C;
+    const bool ln1 = a.stats1 != nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
-    for (int i = tid; i < C; i += NT) { tg[i] = a.gamma[i]; tb[i] = a.beta[i]; }
+    for (int i = tid; i < C; i += NT) {
+        tg[i] = a.gamma[i]; tb[i] = a.beta[i];
+        tg1[i] = ln1 ? a.gamma1[i] : 1.f; tb1[i] = ln1 ? a.beta1[i] : 0.f;
+    }
     for (int idx = tid; idx < C * C; idx += NT) {
         const int k = idx % C, n = idx / C;
         Wl[k * NS + n] = a.w[(long)n * C + k];
@@ -108,6 +115,14 @@ __global__ __launch_bounds__(256, 2) void fcaffn_in_kernel(Args a) {
         for (int s = 0; s < KS; ++s)
             if (s >= s0 && s < s1) dst[s] = bloadv<VEC>(r0, voff, (unsigned)(2 * s) * P4);
     };
+    vf mu1 = 0.f, rs1 = 0.f;
+    auto stats1_issue = [&](const Tile& t) __attribute__((always_inline)) {
+        if (ln1) {
+            const rsrc_t r1 = mk_rsrc(a.stats1 + (long)t.b * 2 * P, 2u * P4);
+            mu1 = bloadv<VEC>(r1, t.pix * 4u, 0u);
+            rs1 = bloadv<VEC>(r1, t.pix * 4u, P4);
+        }
+    };
     auto patch_issue = [&](const Tile& t) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < MS; ++s) {
@@ -124,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void fcaffn_in_kernel(Args a) {
     if (live) {
         strip_issue(a.xi, cur, xa, 0, KS);
         strip_issue(a.x1, cur, xb, 0, KS);
+        stats1_issue(cur);
         patch_issue(cur);
     }
     while (live) {
@@ -138,6 +154,13 @@ __global__ __launch_bounds__(256, 2) void fcaffn_in_kernel(Args a) {
         for (int s = 0; s < KS; ++s) { const vf dl = xa[s] - mean; sq += dl * dl; }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) rstd[v] = 1.0f / sqrtf((sq[v] + __shfl_xor(sq[v], 32)) / (float)C + 1e-5f);
+        if (ln1) {                                                      // x1 = norm3(x): rebuilt from x and its statistics (uniform branch)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                asm volatile("" ::: "memory");
+                xb[s] = (xb[s] - mu1) * rs1 * tg1[2 * s + kh] + tb1[2 * s + kh];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             asm volatile("" ::: "memory");                              // table reads stay here (see conv1x1_smallk_vec_kernel)
@@ -162,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void fcaffn_in_kernel(Args a) {
         const int ntile = tile + gridDim.x;
         const bool nlive = ntile < a.total_tiles;
         const Tile nxt = tile_setup(nlive ? ntile : tile);
-        if (nlive) strip_issue(a.x1, nxt, xb, 0, KS);                  // x1 of the next tile: its registers are free from here on
+        if (nlive) { strip_issue(a.x1, nxt, xb, 0, KS); stats1_issue(nxt); }   // x1 of the next tile: its registers are free from here on
 
         const rsrc_t ro = mk_rsrc(a.out + (long)cur.b * C * P, (unsigned)C * P4);
         const unsigned voff = cur.ok ? (4u * kh * P + cur.pix) * 4u : 0x80000000u;     // outside pixels: stores dropped
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void fcaffn_in_kernel(Args a) {
 template <int NCH, int VEC>
 int launch_fcaffn_in(Args a, hipStream_t s) {
     constexpr int C = 32 * NCH;
-    const size_t lds = (2UL * C + (size_t)C * (C + 1) + 4UL * MS * (C + 1)) * sizeof(float);
+    const size_t lds = (4UL * C + (size_t)C * (C + 1) + 4UL * MS * (C + 1)) * sizeof(float);
     a.tiles_per_img = cdiv((long)a.H * a.W, 4 * 32 * VEC);
     a.total_tiles = a.B * a.tiles_per_img;
     auto kern = fcaffn_in_kernel<NCH, VEC>;
@@ -242,14 +265,16 @@ int launch_fcaffn_in(Args a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int fdn_fcaffn_in(const float* xi, const float* x1, const float* img, const float* w, const float* gamma, const float* beta,
-                             const float* w1_mul, const float* w3_mul, const float* w1_add, const float* w3_add, float* out, int B,
-                             int C, int H, int W, fdn_stream_t stream) {
+extern "C" int fdn_fcaffn_in(const float* xi, const float* x1, const float* stats1, const float* gamma1, const float* beta1,
+                             const float* img, const float* w, const float* gamma, const float* beta, const float* w1_mul,
+                             const float* w3_mul, const float* w1_add, const float* w3_add, float* out, int B, int C, int H, int W,
+                             fdn_stream_t stream) {
+    FDN_CHECK_ARG(!stats1 || (gamma1 && beta1 && (reinterpret_cast<uintptr_t>(stats1) & 7) == 0));
     FDN_CHECK_ARG(xi && x1 && img && w && gamma && beta && w1_mul && w3_mul && w1_add && w3_add && out);
     FDN_CHECK_ARG(B > 0 && H > 0 && W > 1 && (long)H * W < (1L << 28));
     if ((C != 32 && C != 64) || W % 2 != 0) return FDN_ERR_UNSUPPORTED;      // (C = 128: 98 KB of weights leave one wave per SIMD - 0.76 ms against 0.53 unfused)
     if (((reinterpret_cast<uintptr_t>(xi) | reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(out)) & 7) != 0) return FDN_ERR_UNSUPPORTED;
-    Args a = {xi, x1, img, w, gamma, beta, w1_mul, w3_mul, w1_add, w3_add, out, B, C, H, W, 0, 0};
+    Args a = {xi, x1, img, w, gamma, beta, w1_mul, w3_mul, w1_add, w3_add, stats1, gamma1, beta1, out, B, C, H, W, 0, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return C == 32 ? launch_fcaffn_in<1, 2>(a, s) : launch_fcaffn_in<2, 1>(a, s);
 }

@@ -1200,9 +1200,19 @@ struct RowPlan {
     static constexpr size_t lds = ((size_t)RW * RS + NTW) * sizeof(float2);
 };
 
-template <int R1, int P>
+// LN: the input rows are planes of x [B][C][H][W] and the transform is taken of the channel LayerNorm of x
+// ((x - mean) * rstd * gamma_c + beta_c with the per-pixel statistics ln.stats [B][2][H*W]) - FCAFFN's norm3 in front of rfft2
+// (FDN_arch.py:675, :411) without the normalised tensor ever being written.
+struct RowLN {
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    int C, H;
+};
+
+template <int R1, int P, bool LN = false>
 __global__ __launch_bounds__(256, 2) void rfft_rows_rp_kernel(const float* __restrict__ in, float2* __restrict__ out, long R,
-                                                              const float2* __restrict__ tab) {
+                                                              const float2* __restrict__ tab, RowLN lnp) {
     typedef RowPlan<R1, P> L;
     constexpr int M = L::M, W = L::W, Wf = L::Wf, RW = L::RW, CJ = L::CJ, PS = L::PS, RS = L::RS, NJ = L::NJ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1220,6 +1230,24 @@ __global__ __launch_bounds__(256, 2) void rfft_rows_rp_kernel(const float* __res
         const unsigned voff = (unsigned)(rwc * W + 2 * n2) * 4u;
         f2 u[R1];
         sfor<0, R1>([&](auto n1) { u[decltype(n1)::value] = bload_f2(rin, voff, (unsigned)(decltype(n1)::value * P * 8)); });
+        if constexpr (LN) {
+            const long row = row0 + rwc, plane = row / lnp.H;
+            const int h = (int)(row - plane * lnp.H), c = (int)(plane % lnp.C);
+            const long b = plane / lnp.C, HW = (long)lnp.H * W;
+            const __amdgpu_buffer_rsrc_t rs_ = cols_rsrc(lnp.stats + b * 2 * HW, 2 * HW * 4);
+            const unsigned so = (unsigned)(h * W + 2 * n2) * 4u;
+            const float ga = lnp.gamma[c], be = lnp.beta[c];
+            f2 mu[R1], rs[R1];
+            sfor<0, R1>([&](auto n1) {
+                constexpr int N1 = decltype(n1)::value;
+                mu[N1] = bload_f2(rs_, so, (unsigned)(N1 * P * 8));
+                rs[N1] = bload_f2(rs_, so + (unsigned)HW * 4u, (unsigned)(N1 * P * 8));
+            });
+            sfor<0, R1>([&](auto n1) {
+                constexpr int N1 = decltype(n1)::value;
+                u[N1] = (u[N1] - mu[N1]) * rs[N1] * ga + be;
+            });
+        }
         fftr::dft_nat<R1, false>(u);
         sfor<0, R1>([&](auto k1) { Y[rw * RS + decltype(k1)::value * PS + n2] = u[decltype(k1)::value]; });
     }
@@ -1414,13 +1442,19 @@ const float2* get_table_rows_rp(int R1, int P) {
 }
 
 template <int R1, int P>
-int launch_rfft_rp(const float* in, float* out_c, long rows, fdn_stream_t stream) {
+int launch_rfft_rp(const float* in, float* out_c, long rows, fdn_stream_t stream, const RowLN* ln = nullptr) {
     typedef RowPlan<R1, P> L;
     const float2* tab = get_table_rows_rp(R1, P);
     if (!tab) return FDN_ERR_LAUNCH;
-    if (int e = set_lds(rfft_rows_rp_kernel<R1, P>, L::lds)) return e;
-    hipLaunchKernelGGL((rfft_rows_rp_kernel<R1, P>), dim3(cdiv(rows, L::RW)), dim3(256), L::lds, static_cast<hipStream_t>(stream), in,
-                       reinterpret_cast<float2*>(out_c), rows, tab);
+    if (ln) {
+        if (int e = set_lds(rfft_rows_rp_kernel<R1, P, true>, L::lds)) return e;
+        hipLaunchKernelGGL((rfft_rows_rp_kernel<R1, P, true>), dim3(cdiv(rows, L::RW)), dim3(256), L::lds, static_cast<hipStream_t>(stream),
+                           in, reinterpret_cast<float2*>(out_c), rows, tab, *ln);
+        return fdn_launch_status();
+    }
+    if (int e = set_lds(rfft_rows_rp_kernel<R1, P, false>, L::lds)) return e;
+    hipLaunchKernelGGL((rfft_rows_rp_kernel<R1, P, false>), dim3(cdiv(rows, L::RW)), dim3(256), L::lds, static_cast<hipStream_t>(stream), in,
+                       reinterpret_cast<float2*>(out_c), rows, tab, RowLN{});
     return fdn_launch_status();
 }
 
@@ -1511,6 +1545,21 @@ extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fd
                            reinterpret_cast<float2*>(out_c), W, rows, rpb, p, rd);
     }
     return fdn_launch_status();
+}
+
+extern "C" int fdn_rfft_rows_ln(const float* x, const float* stats, const float* gamma, const float* beta, float* out_c, int B, int C,
+                                int H, int W, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && stats && gamma && beta && out_c && B > 0 && C > 0 && H > 0 && W >= 2 && W % 2 == 0);
+    FDN_CHECK_ARG((long)H * W < (1L << 28));
+    int R1 = 0, P = 0;
+    if (!rows_plan(W, &R1, &P) || (reinterpret_cast<uintptr_t>(x) & 7) != 0 || (reinterpret_cast<uintptr_t>(stats) & 7) != 0)
+        return FDN_ERR_UNSUPPORTED;                           // widths with a compile-time plan only: else fdn_layernorm_chan + fdn_rfft_rows
+    const RowLN ln = {stats, gamma, beta, C, H};
+    const long rows = (long)B * C * H;
+#define FDN_CALL(a, b) launch_rfft_rp<a, b>(x, out_c, rows, stream, &ln)
+    FDN_ROWS_DISPATCH(FDN_CALL)
+#undef FDN_CALL
+    return FDN_ERR_UNSUPPORTED;
 }
 
 extern "C" int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane_bins, float* out, long planes, int H, int W,

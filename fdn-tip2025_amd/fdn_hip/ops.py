@@ -308,12 +308,14 @@ def img_mod_maps(img, w1_mul, w3_mul, w1_add, w3_add):
 FCAFFN_IN_C = (32, 64)     # widths fdn_fcaffn_in has a form for
 
 
-def fcaffn_in(xi, x1, img, w, gamma, beta, w1_mul, w3_mul, w1_add, w3_add):
+def fcaffn_in(xi, x1, img, w, gamma, beta, w1_mul, w3_mul, w1_add, w3_add, x1_ln=None):
     """project_in(norm(xi) * x1 + x1) * conv3_mul(conv1_mul(img)) + conv3_add(conv1_add(img)) in one launch (FDN_arch.py:419-423);
-    C in FCAFFN_IN_C, W even."""
+    C in FCAFFN_IN_C, W even.  x1_ln = (stats, gamma, beta): x1 is given un-normalised and its LayerNorm is applied on load."""
     B, C, H, W = xi.shape
     out = torch.empty_like(xi)
-    check(lib().fdn_fcaffn_in(_flat(xi, "xi"), _flat(x1, "x1"), _flat(img, "img"), _flat(w, "w"), _flat(gamma, "gamma"),
+    st1, g1, b1 = x1_ln if x1_ln is not None else (None, None, None)
+    check(lib().fdn_fcaffn_in(_flat(xi, "xi"), _flat(x1, "x1"), _flat(st1, "stats1"), _flat(g1, "gamma1"), _flat(b1, "beta1"),
+                              _flat(img, "img"), _flat(w, "w"), _flat(gamma, "gamma"),
                               _flat(beta, "beta"), _flat(w1_mul, "w1_mul"), _flat(w3_mul, "w3_mul"), _flat(w1_add, "w1_add"),
                               _flat(w3_add, "w3_add"), _flat(out, "out"), B, C, H, W, stream()), "fdn_fcaffn_in")
     return out
@@ -331,6 +333,18 @@ def rfft_rows(x):
     rows = x.numel() // W
     out = torch.empty(x.shape[:-1] + (W // 2 + 1, 2), device=x.device, dtype=torch.float32)
     check(lib().fdn_rfft_rows(_flat(x, "x"), _flat(out, "out"), ctypes.c_long(rows), W, stream()), "fdn_rfft_rows")
+    return out
+
+
+ROWS_PLANNED_W = tuple(2 * r * p for r in (20, 30) for p in (32, 16, 8))     # widths fdn_rfft_rows_ln has a form for
+
+
+def rfft_rows_ln(x, stats, gamma, beta):
+    """rfft along rows of the channel LayerNorm of x [B, C, H, W], normalised on load (fdn_rfft_rows_ln); W in ROWS_PLANNED_W."""
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, H, W // 2 + 1, 2), device=x.device, dtype=torch.float32)
+    check(lib().fdn_rfft_rows_ln(_flat(x, "x"), _flat(stats, "stats"), _flat(gamma, "gamma"), _flat(beta, "beta"), _flat(out, "out"),
+                                 B, C, H, W, stream()), "fdn_rfft_rows_ln")
     return out
 
 

@@ -149,10 +149,12 @@ int fdn_dwconv3x3(const float* x, const float* w, float* out, int B, int C, int 
  * replaces fdn_chan_stats(xi) -> fdn_img_mod_maps(img) -> fdn_conv1x1(FDN_PRO_LN_MULADD, FDN_EPI_MULADD): the LayerNorm statistics
  * come from the activation strip in registers, the two maps are MFMA chains on the image patch (never written to memory).
  * xi, x1, out [B][C][H][W]; img [B][3][H][W]; w [C][C]; gamma, beta [C]; w1_* [C][3]; w3_* [C][9] (all convs without bias).
+ * stats1 / gamma1 / beta1 (all three or none): x1 is the channel LayerNorm of the tensor passed as x1, rebuilt on load from its
+ *   per-pixel statistics [B][2][H*W] - the block's norm3 (FDN_arch.py:675) without a normalised copy in memory.
  * C = 32 or 64, W even, tensors 8-byte aligned; anything else returns FDN_ERR_UNSUPPORTED (use the three calls above). */
-int fdn_fcaffn_in(const float* xi, const float* x1, const float* img, const float* w, const float* gamma, const float* beta,
-                  const float* w1_mul, const float* w3_mul, const float* w1_add, const float* w3_add, float* out, int B, int C,
-                  int H, int W, fdn_stream_t stream);
+int fdn_fcaffn_in(const float* xi, const float* x1, const float* stats1, const float* gamma1, const float* beta1, const float* img,
+                  const float* w, const float* gamma, const float* beta, const float* w1_mul, const float* w3_mul,
+                  const float* w1_add, const float* w3_add, float* out, int B, int C, int H, int W, fdn_stream_t stream);
 
 /* FCAFFN spatial modulation maps (FDN_arch.py:423): mul = conv3_mul(conv1_mul(img)),
  * add = conv3_add(conv1_add(img)).  img [B][3][H][W]; w1_* [C][3]; w3_* [C][9]; outs [B][C][H][W]. */
@@ -171,6 +173,11 @@ int fdn_fft_prepare(int n);
 int fdn_sincos_f32(const float* x, float* sn, float* cs, long n, fdn_stream_t stream);
 /* r2c along rows: in [rows][W] real -> out_c [rows][W/2+1] complex. */
 int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t stream);
+/* r2c along rows of the channel LayerNorm of x, normalised on load: x [B][C][H][W], stats [B][2][H*W] = (mean, rstd) of x over C,
+ * gamma / beta [C] -> out_c [B*C*H][W/2+1] = rfft(norm(x)) (FDN_arch.py:675 + :411).  Widths with a compile-time plan only
+ * (W = 2 * {20, 30} * {32, 16, 8}); else FDN_ERR_UNSUPPORTED: fdn_layernorm_chan + fdn_rfft_rows. */
+int fdn_rfft_rows_ln(const float* x, const float* stats, const float* gamma, const float* beta, float* out_c, int B, int C, int H,
+                     int W, fdn_stream_t stream);
 /* c2r along rows: spectrum rows of `in_row_bins` bins (>= W/2+1; leading-slice crop of
  * irfft2(s=(H,W)), FDN_arch.py:147), planes `in_plane_bins` apart -> out [planes][H][W] real,
  * out = scale * c2r(in) + alpha * res  (res may be NULL).  Im of bins 0 and W/2 is ignored. */

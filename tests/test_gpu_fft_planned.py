@@ -163,3 +163,19 @@ def test_rows_round_trip_at_bench_shape(ops):
     z = ops.rfft_rows(dev(x))
     back = ops.irfft_rows(z, 736, 1280, 2.0 / 1280)
     assert rel_rms(back.cpu(), x) < 2e-6
+
+
+@pytest.mark.parametrize("C,H,W", [(32, 9, 1280), (64, 5, 640), (8, 11, 320), (3, 4, 960)])
+def test_rfft_rows_ln_equals_layernorm_then_rfft(ops, C, H, W):
+    """Row r2c with the channel LayerNorm applied on load against fdn_layernorm_chan -> fdn_rfft_rows and against float64."""
+    B = 2
+    x = _rnd(B, C, H, W, seed=C + W) * 1.7 + 0.4
+    g, b = _rnd(C, seed=1) * 0.3 + 1.0, _rnd(C, seed=2) * 0.2
+    xd = dev(x)
+    got = ops.rfft_rows_ln(xd, ops.chan_stats(xd), dev(g), dev(b))
+    two = ops.rfft_rows(ops.layernorm_chan(xd, dev(g), dev(b)))
+    assert rel_rms(got.cpu(), two.cpu()) < 1e-6
+    x64 = x.double()
+    xn = (x64 - x64.mean(1, keepdim=True)) / torch.sqrt(x64.var(1, unbiased=False, keepdim=True) + 1e-5)
+    xn = xn * g.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
+    assert rel_rms(got.cpu(), torch.view_as_real(torch.fft.rfft(xn, dim=-1))) < 3e-6

@@ -117,6 +117,12 @@ def test_fcaffn_in_equals_unfused(A, C, H, W, B):
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() / ref.abs().max().item() < 4e-6
     assert rel_rms(got.cpu(), ref.cpu()) < 5e-7
+    # x1 given un-normalised with its LayerNorm applied on load (norm3 of the block, FDN_arch.py:675)
+    g1, b1 = dev(_rnd(C, seed=11) * 0.2 + 1.0), dev(_rnd(C, seed=12) * 0.1)
+    raw = dev(_rnd(B, C, H, W, seed=13) * 2.0 + 0.5)
+    via_ln = ops.fcaffn_in(xi, raw, img, w, g, b_, w1m, w3m, w1a, w3a, x1_ln=(ops.chan_stats(raw), g1, b1))
+    via_copy = ops.fcaffn_in(xi, ops.layernorm_chan(raw, g1, b1), img, w, g, b_, w1m, w3m, w1a, w3a)
+    assert (via_ln - via_copy).abs().max().item() / via_copy.abs().max().item() < 4e-6
     # and against plain float64 math (FDN_arch.py:419-423)
     xd, x1d = xi.double().cpu(), x1.double().cpu()
     mu, var = xd.mean(1, keepdim=True), xd.var(1, keepdim=True, unbiased=False)
