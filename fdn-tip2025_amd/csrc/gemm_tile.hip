@@ -35,6 +35,10 @@ struct TArgs {
 template <int PRO>
 __global__ __launch_bounds__(256, 3) void gemm_tile_kernel(TArgs a) {
     const fdn_conv1x1_desc& d = a.d;
+    // LN3_GATE walks K = 3E as triples k' = 3 e + g (g = LayerNorm group): the three k of a triple share one v_value operand and
+    // each has a compile-time group, so a chunk is 10 triples = 30 k (15 MFMA k-steps); the weight rows are gathered to match
+    constexpr bool TRI = PRO == FDN_PRO_LN3_GATE;
+    constexpr int KCH = TRI ? 30 : KC;
     __shared__ float Xs[KC * LS];
     __shared__ float Ws[KC * LS];
     __shared__ float red[2][TP];              // statistics of the result: partial sums of the two channel halves
@@ -43,60 +47,71 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_kernel(TArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, ln = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform BY CONSTRUCTION: keeps k / soffset arithmetic scalar (no waterfall loops)
     const int wi = wave >> 1, wj = wave & 1;   // pixel strips 2 wi, 2 wi + 1; channel tiles 2 wj, 2 wj + 1
-    const int nch = (K + KC - 1) / KC;
+    const int nch = TRI ? (E + 9) / 10 : (K + KC - 1) / KC;
 
     const unsigned S = xcd_contiguous(blockIdx.x, (unsigned)a.total_tiles);
     const int b = (int)(S / (unsigned)a.tiles_per_img);
     const unsigned p0 = (S - (unsigned)b * a.tiles_per_img) * TP;
 
-    // ---- staging roles: x element (k = xr + 2 i, pixel xp), weight element (k = wk, n = wn + 8 i) ----
+    // ---- staging roles: x element (row xr + 2 i | triple xr + 2 i, pixel xp), weight element (row wk, n = wn + 8 i) ----
     const int xp = tid & (TP - 1), xr = wave >> 1;
     const unsigned pix = min(p0 + (unsigned)xp, P - 1);                       // pixels past the image shadow the last one (never stored)
     const int wk = tid & 31, wn = tid >> 5;
     const rsrc_t rx = mk_rsrc(d.x[0] + (long)b * d.xbs[0], (unsigned)K * P4);
-    const rsrc_t rv = mk_rsrc(PRO == FDN_PRO_LN3_GATE ? d.xb + (long)b * d.xbbs : d.x[0], PRO == FDN_PRO_LN3_GATE ? (unsigned)E * P4 : 0u);
+    const rsrc_t rv = mk_rsrc(TRI ? d.xb + (long)b * d.xbbs : d.x[0], TRI ? (unsigned)E * P4 : 0u);
     const rsrc_t rw = mk_rsrc(d.w, (unsigned)(N * K) * 4u);
-    float mu[3] = {0.f, 0.f, 0.f}, rs[3] = {0.f, 0.f, 0.f};
-    if (PRO == FDN_PRO_LN3_GATE) {
+    float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};                  // (x - mean) * rstd = x * sa + sb
+    if (TRI) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             const float* sp = d.stats + ((long)b * 3 + g) * 2 * P;
-            mu[g] = sp[pix];
-            rs[g] = sp[P + pix];
+            sa[g] = sp[P + pix];
+            sb[g] = -sp[pix] * sa[g];
         }
     }
-    float xv[16], vv[16], wv[16];
+    constexpr int NX = TRI ? 15 : 16;
+    float xv[NX], vv[TRI ? 5 : 1], wv[16];
+    float ga[TRI ? 15 : 1], be[TRI ? 15 : 1];     // gamma / beta of the chunk's elements: fetched with it (uniform loads), not between the barriers
     auto fetch = [&](int c) __attribute__((always_inline)) {
-        const int k0 = c * KC;
+        if constexpr (TRI) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k = k0 + xr + 2 * i;                                     // wave-uniform
-            xv[i] = bload(rx, pix * 4u, (unsigned)k * P4);                     // k >= K reads 0
-            if (PRO == FDN_PRO_LN3_GATE) {
-                const int g = k >= 2 * E ? 2 : (k >= E ? 1 : 0);
-                vv[i] = bload(rv, pix * 4u, (unsigned)(k - g * E) * P4);
-            }
-        }
-        const unsigned wo = (k0 + wk < K) ? (unsigned)(wn * K + k0 + wk) * 4u : 0x80000000u;      // past K: outside the descriptor, reads 0
+            for (int i = 0; i < 5; ++i) {
+                const int e = c * 10 + xr + 2 * i;                             // wave-uniform; e >= E reads 0 (v) / finite garbage times 0 (x)
+                vv[i] = bload(rv, pix * 4u, (unsigned)e * P4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) wv[i] = bload(rw, wo, (unsigned)(8 * i * K) * 4u);           // rows n >= N: past the end of w, 0
-    };
-    auto stash = [&](int c) __attribute__((always_inline)) {
-        const int k0 = c * KC;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v = xv[i];
-            if (PRO == FDN_PRO_LN3_GATE) {
-                const int k = k0 + xr + 2 * i;
-                if (k < K) {
-                    const int g = k >= 2 * E ? 2 : (k >= E ? 1 : 0);
-                    const float m_ = g == 0 ? mu[0] : (g == 1 ? mu[1] : mu[2]), r_ = g == 0 ? rs[0] : (g == 1 ? rs[1] : rs[2]);
-                    v = ((v - m_) * r_ * d.gamma[k] + d.beta[k]) * vv[i];     // FDN_arch.py:633-638 (gamma / beta: uniform scalar loads)
-                } else {
-                    v = 0.f;
+                for (int g = 0; g < 3; ++g) {
+                    xv[3 * i + g] = e < E ? bload(rx, pix * 4u, (unsigned)(g * E + e) * P4) : 0.f;
+                    ga[3 * i + g] = e < E ? d.gamma[g * E + e] : 0.f;
+                    be[3 * i + g] = e < E ? d.beta[g * E + e] : 0.f;
                 }
             }
-            Xs[(xr + 2 * i) * LS + xp] = v;
+            const int kq = c * 30 + wk, e = kq / 3, g = kq - 3 * e;            // this thread's weight row k' = 3 e + g -> column g E + e
+            const unsigned wo = (wk < 30 && e < E) ? (unsigned)(wn * K + g * E + e) * 4u : 0x80000000u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wv[i] = bload(rw, wo, (unsigned)(8 * i * K) * 4u);
+        } else {
+            const int k0 = c * KC;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xv[i] = bload(rx, pix * 4u, (unsigned)(k0 + xr + 2 * i) * P4);     // k >= K reads 0
+            const unsigned wo = (k0 + wk < K) ? (unsigned)(wn * K + k0 + wk) * 4u : 0x80000000u;      // past K: outside the descriptor, reads 0
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wv[i] = bload(rw, wo, (unsigned)(8 * i * K) * 4u);           // rows n >= N: past the end of w, 0
+        }
+    };
+    auto stash = [&](int c) __attribute__((always_inline)) {
+        if constexpr (TRI) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int e = c * 10 + xr + 2 * i;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float v = e < E ? fmaf(fmaf(xv[3 * i + g], sa[g], sb[g]), ga[3 * i + g], be[3 * i + g]) * vv[i] : 0.f;   // FDN_arch.py:633-638
+                    Xs[(3 * (xr + 2 * i) + g) * LS + xp] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Xs[(xr + 2 * i) * LS + xp] = xv[i];
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) Ws[wk * LS + wn + 8 * i] = wv[i];
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tile_kernel(TArgs a) {
         const bool more = c + 1 < nch;
         if (more) fetch(c + 1);
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) {
+        for (int s = 0; s < KCH / 2; ++s) {
             const float b0 = xb_[2 * s * LS], b1 = xb_[2 * s * LS + 32];
             const float a0 = wb_[2 * s * LS], a1 = wb_[2 * s * LS + 32];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
