@@ -129,8 +129,12 @@ def describe_call(name, a):
         B, C, H, Wf = (_iv(v) for v in a[4:8])
         b = 4.0 * B * H * Wf * (4 * C + 8)
         key = f"fdn_fft_cols_fcaffn[C={C},{H}x{Wf}]"
+    elif name == "fdn_rfft_rows_ln":
+        B, C, H, W = (_iv(v) for v in a[5:9])
+        b = 4.0 * B * H * (C * (W + 2 * (W // 2 + 1)) + 2 * W)
+        key = f"fdn_rfft_rows_ln[W={W},rows={B * C * H}]"
     elif name == "fdn_fcaffn_in":
-        B, C, H, W = (_iv(v) for v in a[11:15])
+        B, C, H, W = (_iv(v) for v in a[14:18])
         f, b = 2.0 * B * H * W * C * (C + 2 * 27), 4.0 * B * H * W * (3 * C + 3)
         key = f"fdn_fcaffn_in[C={C},{H}x{W}]"
     elif name == "fdn_conv2d":

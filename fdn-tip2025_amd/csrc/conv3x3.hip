@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tiled_kernel(C3Args a, int til
     int b, y0, x0;
     {
         const unsigned T = (unsigned)(tiles_x * tiles_y) * a.B;
-        const unsigned S = xcd_contiguous(blockIdx.x, T);          // neighbouring tiles (shared halo rows / lines) on one XCD
+        const unsigned S0 = xcd_contiguous(blockIdx.x, gridDim.x);  // neighbouring tiles (shared halo rows / lines) on one XCD
+        const unsigned grp = S0 / T, S = S0 - grp * T;              // output-channel group of this workgroup (gridDim.x = groups * T)
+        a.n0 = (int)grp * N;
         const unsigned per = (unsigned)(tiles_x * tiles_y);
         b = (int)(S / per);
         const unsigned t = S - (unsigned)b * per;
@@ -311,7 +313,7 @@ int launch_tiled(const C3Args& a, hipStream_t s) {
     auto kern = conv3x3_tiled_kernel<MT>;
     if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return FDN_ERR_LAUNCH;
     const int tx = cdiv(a.W, TW), ty = cdiv(a.H, TH);
-    const long total = (long)tx * ty * a.B;
+    const long total = (long)tx * ty * a.B * (a.Cout / N);      // one launch: the output-channel groups of 32 * MT are part of the grid
     if (total > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, s, a, tx, ty);
     return fdn_launch_status();
@@ -350,10 +352,7 @@ int fdn_conv3x3_mfma(const float* x, const float* w, const float* bias, const fl
     a.tiles_per_img = a.total_tiles = 0;
     a.n0 = 0; a.CoutT = Cout;
     if (Cin % CK == 0 && Cin >= 2 * CK && (Cout == 32 || Cout % 64 == 0)) {
-        if (Cout == 32) return launch_tiled<1>(a, s);
-        for (a.n0 = 0; a.n0 < Cout; a.n0 += 64)            // wider outputs: 64 channels per launch (four accumulator tiles x two strips spill)
-            if (int e = launch_tiled<2>(a, s)) return e;
-        return FDN_OK;
+        return Cout == 32 ? launch_tiled<1>(a, s) : launch_tiled<2>(a, s);     // wider outputs: groups of 64 channels (four accumulator tiles x two strips spill)
     }
     const int tiles = (Cout + 31) / 32;
     if (tiles == 1) return launch<1, 4>(a, s);
