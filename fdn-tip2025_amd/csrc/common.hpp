@@ -167,14 +167,17 @@ __device__ __forceinline__ void st_load4(float (&v)[4], __amdgpu_buffer_rsrc_t r
         v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
     }
 }
+#ifndef FDN_ST_AUX
+#define FDN_ST_AUX 0      // cache policy bits of the 32-byte row-segment stores (A/B: 2 = non-temporal)
+#endif
 template <bool BF>
 __device__ __forceinline__ void st_store8(const float (&v)[8], __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     if constexpr (BF) {
         __builtin_amdgcn_raw_buffer_store_b128(fdn_u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])},
-                                               r, voff, soff, 0);
+                                               r, voff, soff, FDN_ST_AUX);
     } else {
         __builtin_amdgcn_raw_buffer_store_b128(fdn_u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                               r, voff, soff, 0);
+                                               r, voff, soff, FDN_ST_AUX);
         __builtin_amdgcn_raw_buffer_store_b128(fdn_u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])},
                                                r, voff + 16u, soff, 0);
     }

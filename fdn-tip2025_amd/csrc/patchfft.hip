@@ -358,7 +358,10 @@ constexpr int HALO2 = (TH + 4) * (TW + 4);
 constexpr int HPT2 = (HALO2 + 255) / 256;               // 10 elements per thread
 
 template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as bf16 (fp32 math either way; V4 needs fp32 input)
-__global__ __launch_bounds__(256, 3) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+#ifndef FDN_MID_WGS
+#define FDN_MID_WGS 3
+#endif
+__global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                            const float* __restrict__ w2, const float* __restrict__ ffta,
                                                            const float* __restrict__ fftp, float* __restrict__ out, int Hd,
                                                            int H, int W, int tiles_x, int ntiles) {

@@ -32,8 +32,10 @@ for lvl in (1, 2):
     wh = r(4 * E, C) / C ** .5; dw, fw = r(4 * E, 1, 3, 3), r(E, 1, 1, 8, 5)
     wpk = ops.fdsa_pack(wh, g, b_)
     print(f"L{lvl} fdsa_fused {timeit(lambda: ops.fdsa_fused(x, st, wpk, dw, fw)):.3f} ms", flush=True)
-    if hasattr(ops, "fdffn_fused"):
-        wi = r(Hd, C) / C ** .5
-        w0, w2, fa, fp = r(Hd, 1, 3, 3), r(Hd, 1, 3, 3), r(Hd, 1, 1, 8, 5), r(Hd, 1, 1, 8, 5)
-        pk = ops.fdffn_pack(wi, g, b_)
-        print(f"L{lvl} fdffn_fused {timeit(lambda: ops.fdffn_fused(x, st, pk[0], pk[1], w0, w2, fa, fp)):.3f} ms", flush=True)
+    h = r(B, Hd, H, W)
+    w0, w2, fa, fp = r(Hd, 1, 3, 3), r(Hd, 1, 3, 3), r(Hd, 1, 1, 8, 5), r(Hd, 1, 1, 8, 5)
+    print(f"L{lvl} fdffn_mid {timeit(lambda: ops.fdffn_mid(h, w0, w2, fa, fp)):.3f} ms", flush=True)
+    wg = r(2 * Hd, 1, 3, 3)
+    print(f"L{lvl} dwconv_gate {timeit(lambda: ops.dwconv_gate(h, wg)):.3f} ms", flush=True)
+    hid = r(B, 4 * E, H, W)
+    print(f"L{lvl} fdsa_core {timeit(lambda: ops.fdsa_core(hid, dw, fw)):.3f} ms", flush=True)
