@@ -155,7 +155,8 @@ class FCAFFN(nn.Module):
         """xn: the block input (already norm3-normalised), kept as x1 (FDN_arch.py:410).  ln = (stats, gamma, beta): xn is the
         UN-normalised input and norm3 is applied on load by the row FFT and by fdn_fcaffn_in (no normalised copy)."""
         _, _, h, w = xn.shape
-        z = ops.rfft_rows_ln(xn, *ln) if ln is not None else ops.rfft_rows(xn)
+        wp = ops.spec_pitch(w // 2 + 1)            # spectrum rows padded to whole 128-byte lines for the column pass
+        z = ops.rfft_rows_ln(xn, *ln, pitch=wp) if ln is not None else ops.rfft_rows(xn, pitch=wp)
         ops.fft_cols_fcaffn(z, x_high, xp2, _w(self.conv1_xa.weight), _w(self.conv1_xp.weight))
         xi = ops.irfft_rows(z, h, w, 2.0 / (h * w))
         gam, bet = self.norm.params()

@@ -442,7 +442,7 @@ __device__ void fft_run_inplace(float2* buf, const Plan& p, const float2* tw, in
 // ------------------------------------------------------------------------------------------
 template <bool BIG>
 __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__ in, float2* __restrict__ out, int W, long R,
-                                                       int rpb, const Plan p, const Rader rd) {
+                                                       int rpb, const Plan p, const Rader rd, int pitch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = W / 2, Wf = M + 1;
     float2* A = reinterpret_cast<float2*>(smem);
@@ -546,7 +546,11 @@ __global__ __launch_bounds__(NT) void rfft_rows_kernel(const float* __restrict__
             const float2 w = twl[k * tw1];
             x = make_float2(e.x + (o.x * w.x - o.y * w.y), e.y + (o.x * w.y + o.y * w.x));
         }
-        out[(row0 + s) * Wf + k] = x;
+        out[(row0 + s) * pitch + k] = x;
+    }
+    for (int idx = threadIdx.x; idx < nrow * (pitch - Wf); idx += NT) {         // bins of a padded row past W/2: zeros
+        const int s = idx / (pitch - Wf), k = Wf + idx - s * (pitch - Wf);
+        out[(row0 + s) * pitch + k] = make_float2(0.f, 0.f);
     }
 }
 
@@ -1212,7 +1216,7 @@ struct RowLN {
 
 template <int R1, int P, bool LN = false>
 __global__ __launch_bounds__(256, 2) void rfft_rows_rp_kernel(const float* __restrict__ in, float2* __restrict__ out, long R,
-                                                              const float2* __restrict__ tab, RowLN lnp) {
+                                                              const float2* __restrict__ tab, RowLN lnp, int pitch) {
     typedef RowPlan<R1, P> L;
     constexpr int M = L::M, W = L::W, Wf = L::Wf, RW = L::RW, CJ = L::CJ, PS = L::PS, RS = L::RS, NJ = L::NJ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1281,12 +1285,15 @@ __global__ __launch_bounds__(256, 2) void rfft_rows_rp_kernel(const float* __res
     }
     __syncthreads();
     // split: X[k] = E[k] + W_W^k O[k],  E = (Z[k] + conj Z[M-k]) / 2,  O = -i (Z[k] - conj Z[M-k]) / 2
-    f2* out2 = reinterpret_cast<f2*>(out) + row0 * Wf;
-    const int live = nrow * Wf;
-    const float r_Wf = 1.0f / (float)Wf;
+    // (rows may be padded to `pitch` >= Wf bins - a multiple of 16 keeps every row on a 128-byte line for the column pass; the
+    //  padding is written as zeros)
+    f2* out2 = reinterpret_cast<f2*>(out) + row0 * pitch;
+    const int live = nrow * pitch;
+    const float r_Wf = 1.0f / (float)pitch;
 #pragma unroll 4
     for (int idx = tid; idx < live; idx += 256) {
-        const int s = fdiv(idx, r_Wf), k = idx - s * Wf;
+        const int s = fdiv(idx, r_Wf), k = idx - s * pitch;
+        if (k >= Wf) { out2[idx] = f2{0.f, 0.f}; continue; }
         const f2 zk = Y[s * RS + (k == M ? 0 : k)];
         const f2 zc = Y[s * RS + (k == 0 ? 0 : M - k)];
         const f2 e = 0.5f * f2{zk.x + zc.x, zk.y - zc.y};
@@ -1442,19 +1449,19 @@ const float2* get_table_rows_rp(int R1, int P) {
 }
 
 template <int R1, int P>
-int launch_rfft_rp(const float* in, float* out_c, long rows, fdn_stream_t stream, const RowLN* ln = nullptr) {
+int launch_rfft_rp(const float* in, float* out_c, long rows, fdn_stream_t stream, int pitch, const RowLN* ln = nullptr) {
     typedef RowPlan<R1, P> L;
     const float2* tab = get_table_rows_rp(R1, P);
     if (!tab) return FDN_ERR_LAUNCH;
     if (ln) {
         if (int e = set_lds(rfft_rows_rp_kernel<R1, P, true>, L::lds)) return e;
         hipLaunchKernelGGL((rfft_rows_rp_kernel<R1, P, true>), dim3(cdiv(rows, L::RW)), dim3(256), L::lds, static_cast<hipStream_t>(stream),
-                           in, reinterpret_cast<float2*>(out_c), rows, tab, *ln);
+                           in, reinterpret_cast<float2*>(out_c), rows, tab, *ln, pitch);
         return fdn_launch_status();
     }
     if (int e = set_lds(rfft_rows_rp_kernel<R1, P, false>, L::lds)) return e;
     hipLaunchKernelGGL((rfft_rows_rp_kernel<R1, P, false>), dim3(cdiv(rows, L::RW)), dim3(256), L::lds, static_cast<hipStream_t>(stream), in,
-                       reinterpret_cast<float2*>(out_c), rows, tab, RowLN{});
+                       reinterpret_cast<float2*>(out_c), rows, tab, RowLN{}, pitch);
     return fdn_launch_status();
 }
 
@@ -1517,12 +1524,13 @@ extern "C" int fdn_sincos_f32(const float* x, float* sn, float* cs, long n, fdn_
     return fdn_launch_status();
 }
 
-extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t stream) {
-    FDN_CHECK_ARG(in && out_c && rows > 0 && W >= 2 && W % 2 == 0);
+extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, long out_row_bins, fdn_stream_t stream) {
+    FDN_CHECK_ARG(in && out_c && rows > 0 && W >= 2 && W % 2 == 0 && (out_row_bins == 0 || (out_row_bins >= W / 2 + 1 && out_row_bins < (1L << 20))));
+    const int pitch = out_row_bins ? (int)out_row_bins : W / 2 + 1;
     {
         int R1 = 0, P = 0;
         if (rows_plan(W, &R1, &P) && (reinterpret_cast<uintptr_t>(in) & 7) == 0) {
-#define FDN_CALL(a, b) launch_rfft_rp<a, b>(in, out_c, rows, stream)
+#define FDN_CALL(a, b) launch_rfft_rp<a, b>(in, out_c, rows, stream, pitch)
             FDN_ROWS_DISPATCH(FDN_CALL)
 #undef FDN_CALL
         }
@@ -1538,25 +1546,27 @@ extern "C" int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fd
     if (plan_big(p) || (rader && plan_big(rd.sub))) {
         if (int e = set_lds(rfft_rows_kernel<true>, lds)) return e;
         hipLaunchKernelGGL(rfft_rows_kernel<true>, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream), in,
-                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p, rd);
+                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p, rd, pitch);
     } else {
         if (int e = set_lds(rfft_rows_kernel<false>, lds)) return e;
         hipLaunchKernelGGL(rfft_rows_kernel<false>, dim3(cdiv(rows, rpb)), dim3(NT), lds, static_cast<hipStream_t>(stream), in,
-                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p, rd);
+                           reinterpret_cast<float2*>(out_c), W, rows, rpb, p, rd, pitch);
     }
     return fdn_launch_status();
 }
 
 extern "C" int fdn_rfft_rows_ln(const float* x, const float* stats, const float* gamma, const float* beta, float* out_c, int B, int C,
-                                int H, int W, fdn_stream_t stream) {
+                                int H, int W, long out_row_bins, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && stats && gamma && beta && out_c && B > 0 && C > 0 && H > 0 && W >= 2 && W % 2 == 0);
+    FDN_CHECK_ARG(out_row_bins == 0 || (out_row_bins >= W / 2 + 1 && out_row_bins < (1L << 20)));
+    const int pitch = out_row_bins ? (int)out_row_bins : W / 2 + 1;
     FDN_CHECK_ARG((long)H * W < (1L << 28));
     int R1 = 0, P = 0;
     if (!rows_plan(W, &R1, &P) || (reinterpret_cast<uintptr_t>(x) & 7) != 0 || (reinterpret_cast<uintptr_t>(stats) & 7) != 0)
         return FDN_ERR_UNSUPPORTED;                           // widths with a compile-time plan only: else fdn_layernorm_chan + fdn_rfft_rows
     const RowLN ln = {stats, gamma, beta, C, H};
     const long rows = (long)B * C * H;
-#define FDN_CALL(a, b) launch_rfft_rp<a, b>(x, out_c, rows, stream, &ln)
+#define FDN_CALL(a, b) launch_rfft_rp<a, b>(x, out_c, rows, stream, pitch, &ln)
     FDN_ROWS_DISPATCH(FDN_CALL)
 #undef FDN_CALL
     return FDN_ERR_UNSUPPORTED;
@@ -1594,22 +1604,31 @@ extern "C" int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane
 }
 
 __global__ __launch_bounds__(256) void pack_guidance_kernel(const float* __restrict__ amp, const float* __restrict__ pha,
-                                                            float4* __restrict__ out, long bins, long total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // (b, h, w) flat
+                                                            float4* __restrict__ out, int H, int Wf, int pitch, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // (b, h, w) flat over padded rows
     if (i >= total) return;
-    const long b = i / bins, o = i - b * bins;
+    const long row = i / pitch;
+    const int w = (int)(i - row * pitch);
+    if (w >= Wf) {                                                  // padding of a row: zeros (phase 0, amplitude 0)
+        out[2 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        out[2 * i + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const long b = row / H, bins = (long)H * Wf, o = (row - b * H) * Wf + w;
     const float* ap = amp + b * 3 * bins + o;
     const float* pp = pha + b * 3 * bins + o;
     out[2 * i] = make_float4(ap[0], ap[bins], ap[2 * bins], pp[0]);
     out[2 * i + 1] = make_float4(pp[bins], pp[2 * bins], 0.f, 0.f);
 }
 
-extern "C" int fdn_pack_guidance(const float* amp, const float* pha, float* packed, int B, int H, int Wf, fdn_stream_t stream) {
-    FDN_CHECK_ARG(amp && pha && packed && B > 0 && H > 0 && Wf > 0);
+extern "C" int fdn_pack_guidance(const float* amp, const float* pha, float* packed, int B, int H, int Wf, long row_bins,
+                                 fdn_stream_t stream) {
+    FDN_CHECK_ARG(amp && pha && packed && B > 0 && H > 0 && Wf > 0 && (row_bins == 0 || (row_bins >= Wf && row_bins < (1L << 20))));
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 15) == 0);
-    const long bins = (long)H * Wf, total = bins * B;
+    const int pitch = row_bins ? (int)row_bins : Wf;
+    const long total = (long)B * H * pitch;
     hipLaunchKernelGGL(pack_guidance_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), amp,
-                       pha, reinterpret_cast<float4*>(packed), bins, total);
+                       pha, reinterpret_cast<float4*>(packed), H, Wf, pitch, total);
     return fdn_launch_status();
 }
 

@@ -327,24 +327,29 @@ def fcaffn_in(xi, x1, img, w, gamma, beta, w1_mul, w3_mul, w1_add, w3_add, x1_ln
 RS_BILINEAR_HALF, RS_BILINEAR_X2, RS_NEAREST_HALF, RS_NEAREST_X2, RS_PIXEL_UNSHUFFLE = 0, 1, 2, 3, 4
 
 
-def rfft_rows(x):
-    """real [..., H, W] -> interleaved complex [..., H, W//2+1, 2] along the last axis."""
+def spec_pitch(Wf):
+    """Row pitch (bins) that starts every spectrum row on a 128-byte line: the column pass then runs on the padded width."""
+    return (Wf + 15) // 16 * 16
+
+
+def rfft_rows(x, pitch=None):
+    """real [..., H, W] -> interleaved complex [..., H, pitch or W//2+1, 2] along the last axis (bins past W//2 are zeros)."""
     W = x.shape[-1]
     rows = x.numel() // W
-    out = torch.empty(x.shape[:-1] + (W // 2 + 1, 2), device=x.device, dtype=torch.float32)
-    check(lib().fdn_rfft_rows(_flat(x, "x"), _flat(out, "out"), ctypes.c_long(rows), W, stream()), "fdn_rfft_rows")
+    out = torch.empty(x.shape[:-1] + (pitch or W // 2 + 1, 2), device=x.device, dtype=torch.float32)
+    check(lib().fdn_rfft_rows(_flat(x, "x"), _flat(out, "out"), ctypes.c_long(rows), W, ctypes.c_long(pitch or 0), stream()), "fdn_rfft_rows")
     return out
 
 
 ROWS_PLANNED_W = tuple(2 * r * p for r in (20, 30) for p in (32, 16, 8))     # widths fdn_rfft_rows_ln has a form for
 
 
-def rfft_rows_ln(x, stats, gamma, beta):
+def rfft_rows_ln(x, stats, gamma, beta, pitch=None):
     """rfft along rows of the channel LayerNorm of x [B, C, H, W], normalised on load (fdn_rfft_rows_ln); W in ROWS_PLANNED_W."""
     B, C, H, W = x.shape
-    out = torch.empty((B, C, H, W // 2 + 1, 2), device=x.device, dtype=torch.float32)
+    out = torch.empty((B, C, H, pitch or W // 2 + 1, 2), device=x.device, dtype=torch.float32)
     check(lib().fdn_rfft_rows_ln(_flat(x, "x"), _flat(stats, "stats"), _flat(gamma, "gamma"), _flat(beta, "beta"), _flat(out, "out"),
-                                 B, C, H, W, stream()), "fdn_rfft_rows_ln")
+                                 B, C, H, W, ctypes.c_long(pitch or 0), stream()), "fdn_rfft_rows_ln")
     return out
 
 
@@ -366,23 +371,25 @@ def sincos(x):
     return sn, cs
 
 
-def pack_guidance(amp, pha):
-    """(amp, pha) [B,3,H,Wf] -> one 32-byte record per bin [B,H,Wf,8] (fdn_pack_guidance).  The guidance of a
+def pack_guidance(amp, pha, pitch=None):
+    """(amp, pha) [B,3,H,Wf] -> one 32-byte record per bin [B,H,pitch or Wf,8] (fdn_pack_guidance).  The guidance of a
     level is shared by all its encoder blocks, so the packed copy is memoised on the amp tensor object."""
-    cached = getattr(amp, "_fdn_packed", None)
-    if cached is not None and cached[0] is pha:
-        return cached[1]
     B, _, H, Wf = amp.shape
-    out = torch.empty((B, H, Wf, 8), device=amp.device, dtype=torch.float32)
-    check(lib().fdn_pack_guidance(_flat(amp, "amp"), _flat(pha, "pha"), _flat(out, "packed"), B, H, Wf, stream()),
+    pitch = pitch or Wf
+    cached = getattr(amp, "_fdn_packed", None)
+    if cached is not None and cached[0] is pha and cached[1].shape[2] == pitch:
+        return cached[1]
+    out = torch.empty((B, H, pitch, 8), device=amp.device, dtype=torch.float32)
+    check(lib().fdn_pack_guidance(_flat(amp, "amp"), _flat(pha, "pha"), _flat(out, "packed"), B, H, Wf, ctypes.c_long(pitch), stream()),
           "fdn_pack_guidance")
     amp._fdn_packed = (pha, out)
     return out
 
 
 def fft_cols_fcaffn(z, amp, pha, wxa, wxp):
+    """z [B, C, H, Wz, 2] with Wz >= the guidance width (a padded spectrum: the guidance is packed with the same pitch)."""
     B, C, H, Wf, _ = z.shape
-    guide = pack_guidance(amp, pha)
+    guide = pack_guidance(amp, pha, pitch=Wf)
     check(lib().fdn_fft_cols_fcaffn(_flat(z, "z"), _flat(guide, "guide"), _flat(wxa, "wxa"), _flat(wxp, "wxp"), B, C, H, Wf,
                                     stream()), "fdn_fft_cols_fcaffn")
     return z

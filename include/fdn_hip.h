@@ -171,22 +171,26 @@ int fdn_fft_prepare(int n);
  * kernels evaluate for torch.cos / torch.sin at FDN_arch.py:95-97, :414-416): ~1 ulp over the whole float range, NaN for
  * Inf / NaN.  Exposed so the tests can pin it against a float64 reference at large arguments. */
 int fdn_sincos_f32(const float* x, float* sn, float* cs, long n, fdn_stream_t stream);
-/* r2c along rows: in [rows][W] real -> out_c [rows][W/2+1] complex. */
-int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, fdn_stream_t stream);
+/* r2c along rows: in [rows][W] real -> out_c [rows][out_row_bins] complex, bins W/2+1 .. out_row_bins-1 of a row written as zeros
+ * (out_row_bins = 0: dense rows of W/2+1).  A pitch that is a multiple of 16 bins starts every spectrum row on a 128-byte line:
+ * the column pass then runs on the padded width (its tiles no longer straddle lines: 1.08 -> 0.80 ms at level 1) and
+ * fdn_irfft_rows takes the pitch as in_row_bins. */
+int fdn_rfft_rows(const float* in, float* out_c, long rows, int W, long out_row_bins, fdn_stream_t stream);
 /* r2c along rows of the channel LayerNorm of x, normalised on load: x [B][C][H][W], stats [B][2][H*W] = (mean, rstd) of x over C,
  * gamma / beta [C] -> out_c [B*C*H][W/2+1] = rfft(norm(x)) (FDN_arch.py:675 + :411).  Widths with a compile-time plan only
  * (W = 2 * {20, 30} * {32, 16, 8}); else FDN_ERR_UNSUPPORTED: fdn_layernorm_chan + fdn_rfft_rows. */
 int fdn_rfft_rows_ln(const float* x, const float* stats, const float* gamma, const float* beta, float* out_c, int B, int C, int H,
-                     int W, fdn_stream_t stream);
+                     int W, long out_row_bins, fdn_stream_t stream);
 /* c2r along rows: spectrum rows of `in_row_bins` bins (>= W/2+1; leading-slice crop of
  * irfft2(s=(H,W)), FDN_arch.py:147), planes `in_plane_bins` apart -> out [planes][H][W] real,
  * out = scale * c2r(in) + alpha * res  (res may be NULL).  Im of bins 0 and W/2 is ignored. */
 int fdn_irfft_rows(const float* in_c, long in_row_bins, long in_plane_bins, float* out, long planes, int H, int W,
                    float scale, const float* res, float alpha, fdn_stream_t stream);
 /* Interleave the FCAFFN guidance (x_high = amplitude, xp2 = phase, FDN_arch.py:413-414; both [B][3][H][Wf]) into
- * one 32-byte record per bin: packed [B][H][Wf][8] = (amp0, amp1, amp2, pha0, pha1, pha2, 0, 0).  Done once per
- * level and forward; every encoder block of the level reads it (a column tile's rows become contiguous). */
-int fdn_pack_guidance(const float* amp, const float* pha, float* packed, int B, int H, int Wf, fdn_stream_t stream);
+ * one 32-byte record per bin: packed [B][H][row_bins][8] = (amp0, amp1, amp2, pha0, pha1, pha2, 0, 0), records Wf .. row_bins-1 of a
+ * row zero (row_bins = 0: dense rows of Wf; use the spectrum's pitch, see fdn_rfft_rows).  Done once per level and forward; every
+ * encoder block of the level reads it (a column tile's rows become contiguous). */
+int fdn_pack_guidance(const float* amp, const float* pha, float* packed, int B, int H, int Wf, long row_bins, fdn_stream_t stream);
 /* FCAFFN spectral core, in place on z [B*C][H][Wf] (already row-transformed): column FFT ->
  * replace_denormals -> * conv1_xa(amp) * exp(-i conv1_xp(pha)) -> column iFFT (FDN_arch.py:411-418,
  * SURVEY App. C).  guide = fdn_pack_guidance output; wxa,wxp [C][3].  Unscaled (scale in fdn_irfft_rows). */

@@ -179,3 +179,32 @@ def test_rfft_rows_ln_equals_layernorm_then_rfft(ops, C, H, W):
     xn = (x64 - x64.mean(1, keepdim=True)) / torch.sqrt(x64.var(1, unbiased=False, keepdim=True) + 1e-5)
     xn = xn * g.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
     assert rel_rms(got.cpu(), torch.view_as_real(torch.fft.rfft(xn, dim=-1))) < 3e-6
+
+
+@pytest.mark.parametrize("W,rows", [(1280, 19), (640, 5), (26, 7), (1282, 3)])
+def test_rfft_rows_padded_pitch(ops, W, rows):
+    """Rows written with a pitch of whole 128-byte lines (planned and generic kernels): the bins are the dense result, the padding zeros."""
+    x = _rnd(1, 1, rows, W, seed=W)
+    Wf = W // 2 + 1
+    pitch = ops.spec_pitch(Wf)
+    z = ops.rfft_rows(dev(x), pitch=pitch)
+    assert z.shape[-2] == pitch
+    dense = ops.rfft_rows(dev(x))
+    assert torch.equal(z[..., :Wf, :], dense)
+    assert z[..., Wf:, :].abs().max().item() == 0.0 if pitch > Wf else True
+
+
+def test_fcaffn_chain_with_padded_spectrum(ops):
+    """rfft (padded rows) -> column pass on the padded width -> irfft with the pitch as row stride equals the dense chain."""
+    B, C, H, W = 1, 8, 184, 320
+    x = _rnd(B, C, H, W, seed=9)
+    Wf = W // 2 + 1
+    amp = _rnd(B, 3, H, Wf, seed=10).abs()
+    pha = (torch.rand(B, 3, H, Wf, generator=torch.Generator().manual_seed(11)) * 2 - 1) * math.pi
+    wxa, wxp = _rnd(C, 3, seed=12), _rnd(C, 3, seed=13)
+    outs = []
+    for pitch in (None, ops.spec_pitch(Wf)):
+        z = ops.rfft_rows(dev(x), pitch=pitch)
+        ops.fft_cols_fcaffn(z, dev(amp), dev(pha), dev(wxa), dev(wxp))
+        outs.append(ops.irfft_rows(z, H, W, 2.0 / (H * W)))
+    assert rel_rms(outs[1].cpu(), outs[0].cpu()) < 1e-6

@@ -49,7 +49,7 @@ def test_ctypes_prototypes_match_header(lib):
 def test_argument_validation_without_gpu(lib):
     # NULL pointers / bad sizes are rejected before any launch
     assert lib.fdn_fdsa_core(None, None, None, None, 1, 38, 32, 32, None) == 1
-    assert lib.fdn_rfft_rows(None, None, ctypes.c_long(4), 16, None) == 1
+    assert lib.fdn_rfft_rows(None, None, ctypes.c_long(4), 16, ctypes.c_long(0), None) == 1
 
 
 def test_state_dict_layout_matches_reference():
