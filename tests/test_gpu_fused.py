@@ -132,3 +132,23 @@ def test_fcaffn_in_equals_unfused(A, C, H, W, B):
     m64 = F.conv2d(F.conv2d(img.double().cpu(), w1m.double().cpu().view(C, 3, 1, 1)), w3m.double().cpu().view(C, 1, 3, 3), padding=1, groups=C)
     a64 = F.conv2d(F.conv2d(img.double().cpu(), w1a.double().cpu().view(C, 3, 1, 1)), w3a.double().cpu().view(C, 1, 3, 3), padding=1, groups=C)
     assert rel_rms(got.cpu(), t * m64 + a64) < 2e-6
+
+
+def test_fcaffn_in_beyond_4m_pixels(A):
+    """More than 2^22 pixels per image: the pixel -> (row, column) split of the image-patch borders leaves the exact
+    float-reciprocal range and takes the integer division."""
+    from fdn_hip import ops
+    C, H, W, B = 32, 2052, 2048, 1
+    xi, x1 = dev(_rnd(B, C, H, W, seed=1)), dev(_rnd(B, C, H, W, seed=2))
+    img = dev(torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3)))
+    w = dev(_rnd(C, C, seed=4) / C ** 0.5)
+    g, b_ = dev(_rnd(C, seed=5) * 0.2 + 1.0), dev(_rnd(C, seed=6) * 0.1)
+    w1m, w3m = dev(_rnd(C, 3, seed=7)), dev(_rnd(C, 9, seed=8) / 3)
+    w1a, w3a = dev(_rnd(C, 3, seed=9)), dev(_rnd(C, 9, seed=10) / 3)
+    mul, add = ops.img_mod_maps(img, w1m, w3m, w1a, w3a)
+    ref = ops.conv1x1(xi, w, ln_muladd=(ops.chan_stats(xi), g, b_, x1), muladd=(mul, add))
+    got = ops.fcaffn_in(xi, x1, img, w, g, b_, w1m, w3m, w1a, w3a)
+    torch.cuda.synchronize()
+    # rows 2046..2051 lie past pixel 2^22: compare there and at the image borders of those rows
+    assert (got[..., 2040:, :] - ref[..., 2040:, :]).abs().max().item() / ref.abs().max().item() < 4e-6
+    assert (got[..., :8, :] - ref[..., :8, :]).abs().max().item() / ref.abs().max().item() < 4e-6
