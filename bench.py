@@ -225,7 +225,7 @@ def kernel_roofline(key, rec, traffic):
 
 def pmc_traffic_by_group():
     """HBM bytes per launch of each kernel group from the committed rocprofv3 PMC passes (the newest
-    profiles/*traffic_groups.json, written by tools/pmc_groups.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs over one
+    profiles/*traffic_groups.json, written by tools/profile_merge.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs over one
     launch of each group, corrected per load form as that file documents).  {} when no profile is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_groups.json")))
