@@ -848,14 +848,29 @@ __device__ __forceinline__ void bstore_f2(f2 v, __amdgpu_buffer_rsrc_t r, unsign
     __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, voff, soff, 0);
 }
 
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kernel), bytes)) return FDN_ERR_LAUNCH;
+    return FDN_OK;
+}
+
+// R may be composite (34 = 2 * 17 for the 1088 rows of 1080p level 1: dft_nat<R>); R * 8 jobs then exceed 256 threads and the
+// workgroup gets a fifth wave that only takes part in the P-point stage.
+template <int R, int P> struct ColPlan {
+    static constexpr int NJ = R * 8, NT = NJ > 256 ? 320 : 256, KS = 256 + 4;
+    static constexpr size_t lds = ((size_t)R * KS + (size_t)(P - 1) * R) * sizeof(float2);
+};
+
 template <int R, int P, int MODE>
-__global__ __launch_bounds__(256, 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
-    constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = 256 + 4, NJ = R * NG;
+__global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
+    constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = ColPlan<R, P>::KS, NJ = R * NG, NT = ColPlan<R, P>::NT;
     static_assert(TC / CJ == NG, "8 column groups");
-    __shared__ f2 Y[R * KS];
-    __shared__ f2 twl[(P - 1) * R];                 // twl[(n2 - 1) * R + k1] = W_H^{n2 k1}, n2 >= 1  (3 workgroups per CU: 53.5 KB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cols[];
+    f2* Y = reinterpret_cast<f2*>(smem_cols);       // [R][KS]
+    f2* twl = Y + R * KS;                           // twl[(n2 - 1) * R + k1] = W_H^{n2 k1}, n2 >= 1  (R = 23: 53.5 KB)
     const int tid = threadIdx.x, Wf = a.Wf;
-    for (int i = tid; i < (P - 1) * R; i += 256) twl[i] = f2{twT[R + i].x, twT[R + i].y};
+    const bool io = NT == 256 || tid < 256;         // threads with a (row class, column) of the tile
+    for (int i = tid; i < (P - 1) * R; i += NT) twl[i] = f2{twT[R + i].x, twT[R + i].y};
     // work order: every XCD walks a contiguous run of items ordered (batch, chunk of 8 channels, column tile, channel in chunk):
     // the tiles either side of a shared 128-byte line run within a few workgroups of each other on one L2, and the guidance
     // records of a tile (shared by all channels of a batch item) are re-read from memory once per chunk only
@@ -874,21 +889,22 @@ __global__ __launch_bounds__(256, 2) void fft_cols_rp_kernel(ColArgs a, const fl
         const long b = rest / nchunk;
         plane = (int)(b * C + (rest - b * nchunk) * CH + ci);
     }
-    const int c = tid & (TC - 1), n2 = tid / TC;
+    const int c = tid & (TC - 1), n2 = (tid & 255) / TC;
     const bool live = col0 + c < Wf;
     const int col = live ? col0 + c : Wf - 1;                                // dead lanes shadow the last column (columns never mix)
     const long plane_bins = (long)H * Wf;                                     // < 2^28: byte offsets inside a plane fit 32 bits
     const __amdgpu_buffer_rsrc_t rz = cols_rsrc(a.z + (long)plane * plane_bins, plane_bins * 8);
     const unsigned zoff = (unsigned)(n2 * Wf + col) * 8u, zstep = (unsigned)(P * Wf) * 8u;
 
-    if (MODE != COL_INV_POLAR) {
+    if (MODE != COL_INV_POLAR && io) {
         f2 u[R];
         sfor<0, R>([&](auto n1) { u[decltype(n1)::value] = bload_f2(rz, zoff, (unsigned)decltype(n1)::value * zstep); });
-        fftr::dft_odd_c<R, false>(u);
+        fftr::dft_nat<R, false>(u);
         sfor<0, R>([&](auto k1) { Y[decltype(k1)::value * KS + tid] = u[decltype(k1)::value]; });
     }
 
-    const int jt = (tid + 64 * (int)(blockIdx.x >> 3)) & 255;
+    int jt = tid + 64 * (int)((blockIdx.x >> 3) % (NT / 64));
+    if (jt >= NT) jt -= NT;
     const bool worker = jt < NJ;
     const int k1 = worker ? jt >> 3 : 0, cg = jt & 7;
     // column of value slot q (q / P = column inside the group): clamped like `col`
@@ -1031,10 +1047,10 @@ __global__ __launch_bounds__(256, 2) void fft_cols_rp_kernel(ColArgs a, const fl
         return;
     }
     __syncthreads();
-    {
+    if (io) {
         f2 u[R];
         sfor<0, R>([&](auto k) { u[decltype(k)::value] = Y[decltype(k)::value * KS + tid]; });
-        fftr::dft_odd_c<R, true>(u);
+        fftr::dft_nat<R, true>(u);
         if (live) sfor<0, R>([&](auto n1) { bstore_f2(u[decltype(n1)::value], rz, zoff, (unsigned)decltype(n1)::value * zstep); });
     }
 }
@@ -1082,8 +1098,11 @@ int launch_cols_rp(ColArgs a, long planes, fdn_stream_t stream) {
     constexpr int TC = 256 / P;
     const long total = (long)cdiv(a.Wf, TC) * planes, per_xcd = (total + 7) / 8;
     if (per_xcd * 8 > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((fft_cols_rp_kernel<R, P, MODE>), dim3((unsigned)(per_xcd * 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       a, tw);
+    typedef ColPlan<R, P> CP;
+    constexpr size_t lds = CP::lds;
+    constexpr int nt = CP::NT;
+    if (int e = set_lds(fft_cols_rp_kernel<R, P, MODE>, lds)) return e;
+    hipLaunchKernelGGL((fft_cols_rp_kernel<R, P, MODE>), dim3((unsigned)(per_xcd * 8)), dim3(nt), lds, static_cast<hipStream_t>(stream), a, tw);
     return fdn_launch_status();
 }
 
@@ -1098,6 +1117,7 @@ int launch_cols_planned(const ColArgs& a, long planes, fdn_stream_t stream, bool
         case 17 * 32: return launch_cols_rp<17, 32, MODE>(a, planes, stream);
         case 17 * 16: return launch_cols_rp<17, 16, MODE>(a, planes, stream);
         case 17 * 8: return launch_cols_rp<17, 8, MODE>(a, planes, stream);
+        case 34 * 32: return launch_cols_rp<34, 32, MODE>(a, planes, stream);       // 1088 rows: 1080p level 1
         default: break;
     }
     *done = false;
@@ -1119,11 +1139,6 @@ int pick_tc(int H) {
     return 0;
 }
 
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kernel), bytes)) return FDN_ERR_LAUNCH;
-    return FDN_OK;
-}
 
 int pick_rpb(int M) {
     // rows per workgroup from an LDS budget for the ping-pong buffers.  Swept on the B=8 720p forward (row kernels, ms per
@@ -1503,6 +1518,7 @@ extern "C" int fdn_fft_prepare(int n) {
     for (int R : {23, 17})
         for (int P : {32, 16, 8})
             if (n == R * P && !get_table_rp(R, P)) return FDN_ERR_LAUNCH;      // column lengths with a compile-time plan
+    if (n == 34 * 32 && !get_table_rp(34, 32)) return FDN_ERR_LAUNCH;
     return get_table(n) ? FDN_OK : FDN_ERR_LAUNCH;
 }
 

@@ -1,5 +1,5 @@
 """GPU tests of the column FFT kernels with a compile-time plan (H = 23 * {32,16,8}: the 720p pyramid, 17 * {32,16,8}: 1080p
-levels 2-3) against torch.fft in float64, in all three modes, with partial column tiles, and of the sin / cos the modulation
+levels 2-3, 34 * 32 = 1088: 1080p level 1) against torch.fft in float64, in all three modes, with partial column tiles, and of the sin / cos the modulation
 evaluates (large arguments take the table-driven reduction and, inside the FCAFFN kernel, the cold second pass)."""
 import math
 
@@ -11,7 +11,7 @@ from common import rel_rms
 
 pytestmark = pytest.mark.gpu
 
-PLANNED_H = [736, 368, 184, 544, 272, 136]
+PLANNED_H = [736, 368, 184, 544, 272, 136, 1088]
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +85,7 @@ def _fcaffn_ref(z, amp, pha, wxa, wxp):
     return torch.view_as_real(torch.fft.ifft(out, dim=2) * Z.shape[2])
 
 
-@pytest.mark.parametrize("H,C,Wf", [(736, 8, 73), (368, 16, 161), (184, 8, 161), (544, 8, 20), (272, 3, 9), (136, 16, 33)])
+@pytest.mark.parametrize("H,C,Wf", [(736, 8, 73), (368, 16, 161), (184, 8, 161), (544, 8, 20), (272, 3, 9), (136, 16, 33), (1088, 8, 41)])
 def test_cols_fcaffn_matches_reference_math(ops, H, C, Wf):
     B = 2
     z = _rnd(B, C, H, Wf, 2, seed=H)
