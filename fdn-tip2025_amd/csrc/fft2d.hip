@@ -1519,6 +1519,10 @@ extern "C" int fdn_fft_prepare(int n) {
         for (int P : {32, 16, 8})
             if (n == R * P && !get_table_rp(R, P)) return FDN_ERR_LAUNCH;      // column lengths with a compile-time plan
     if (n == 34 * 32 && !get_table_rp(34, 32)) return FDN_ERR_LAUNCH;
+    {
+        int R1 = 0, P = 0;                                                      // row widths with a compile-time plan
+        if (rows_plan(n, &R1, &P) && !get_table_rows_rp(R1, P)) return FDN_ERR_LAUNCH;
+    }
     return get_table(n) ? FDN_OK : FDN_ERR_LAUNCH;
 }
 

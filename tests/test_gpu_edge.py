@@ -242,3 +242,19 @@ def test_graphed_forward_bit_identical(A):
         x = dev(torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(3)))
         eager = net(x, ratio_i=lp(x))[0]
     assert torch.equal(g(x), eager)
+
+
+def test_graphed_forward_planned_fft_shape(A):
+    """Capture at a shape that takes the compile-time-plan FFT kernels, the padded spectrum rows, fdn_fcaffn_in and
+    fdn_rfft_rows_ln (W = 320, H = 184 * 4 ... here 736 x 320: level-1 rows 320 and columns 736 are planned): the tables those kernels
+    build on first use must exist before the capture starts (the warm-up forward does it)."""
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from fdn_hip.pipeline import GraphedForward
+    net = load(A.FDN(), fdn_weights(tame=0.03))
+    lp = load(I_predict_net(), lpnet_weights())
+    g = GraphedForward(net, lp)
+    x = dev(torch.rand(1, 3, 736, 320, generator=torch.Generator().manual_seed(5)))
+    with torch.no_grad():
+        eager = net(x, ratio_i=lp(x))[0]
+    assert torch.equal(g(x), eager)
+    assert torch.equal(g(x), eager)
