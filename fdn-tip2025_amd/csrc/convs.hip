@@ -227,6 +227,51 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     }
 }
 
+// Four outputs per thread for the bilinear modes and nearest x2 (16-byte stores, the source window loaded once): the same arithmetic
+// per value as resample_kernel, so the results are bit-identical to it.  grid = ((output rows x column quads) / 256, planes).
+template <int MODE>
+__global__ __launch_bounds__(256) void resample4_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int OH,
+                                                        int OW) {
+    // (row, quad) flattened over the threads of a plane: a row of OW / 4 quads rarely fills whole 256-thread blocks
+    const int OWq = OW >> 2;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)(OH * OWq)) return;
+    const int oy = idx < (1u << 22) ? (int)(((float)idx + 0.5f) * (1.0f / (float)OWq)) : (int)(idx / (unsigned)OWq);   // exact below 2^22
+    const int t = (int)idx - oy * OWq;
+    const long pl = blockIdx.y;
+    const float* s = x + pl * H * W;
+    float4 o;
+    if (MODE == FDN_RS_NEAREST_X2) {
+        const float2 v = *reinterpret_cast<const float2*>(s + (long)(oy >> 1) * W + 2 * t);
+        o = make_float4(v.x, v.x, v.y, v.y);
+    } else if (MODE == FDN_RS_BILINEAR_HALF) {
+        const float4 a0 = *reinterpret_cast<const float4*>(s + (long)(2 * oy) * W + 8 * t);
+        const float4 a1 = *reinterpret_cast<const float4*>(s + (long)(2 * oy) * W + 8 * t + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(s + (long)(2 * oy + 1) * W + 8 * t);
+        const float4 b1 = *reinterpret_cast<const float4*>(s + (long)(2 * oy + 1) * W + 8 * t + 4);
+        o.x = 0.5f * (0.5f * a0.x + 0.5f * a0.y) + 0.5f * (0.5f * b0.x + 0.5f * b0.y);
+        o.y = 0.5f * (0.5f * a0.z + 0.5f * a0.w) + 0.5f * (0.5f * b0.z + 0.5f * b0.w);
+        o.z = 0.5f * (0.5f * a1.x + 0.5f * a1.y) + 0.5f * (0.5f * b1.x + 0.5f * b1.y);
+        o.w = 0.5f * (0.5f * a1.z + 0.5f * a1.w) + 0.5f * (0.5f * b1.z + 0.5f * b1.w);
+    } else {
+        // align_corners=False x2: source x of output 4t + j is 2t + (2j - 1) / 4; the four outputs read columns 2t-1 .. 2t+2
+        const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, y1 = min(y0 + 1, H - 1);
+        const float ly = sy - y0;
+        const float* r0 = s + (long)y0 * W;
+        const float* r1 = s + (long)y1 * W;
+        const int cm = max(2 * t - 1, 0), c0 = 2 * t, c1 = min(2 * t + 1, W - 1), c2 = min(2 * t + 2, W - 1);
+        const float am = r0[cm], a0 = r0[c0], a1 = r0[c1], a2 = r0[c2];
+        const float bm = r1[cm], b0 = r1[c0], b1 = r1[c1], b2 = r1[c2];
+        auto mix = [&](float lx, float p, float q, float u, float v) { return (1.f - ly) * ((1.f - lx) * p + lx * q) + ly * ((1.f - lx) * u + lx * v); };
+        o.x = t == 0 ? mix(0.f, a0, a1, b0, b1) : mix(0.75f, am, a0, bm, b0);      // (output 0 of a row: source x clamps to 0)
+        o.y = mix(0.25f, a0, a1, b0, b1);
+        o.z = mix(0.75f, a0, a1, b0, b1);
+        o.w = mix(0.25f, a1, a2, b1, b2);
+    }
+    *reinterpret_cast<float4*>(out + (pl * OH + oy) * OW + 4 * t) = o;
+}
+
 // fourier_fuse.fpre[1]: Conv2d(n, n, 1, padding=1, groups=n): (H+2)x(W+2) map, bias-only border
 __global__ __launch_bounds__(256) void dw1x1_pad1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out, int C, int H,
@@ -368,6 +413,19 @@ extern "C" int fdn_resample(const float* x, float* out, long planes, int H, int 
         const long np = oplanes - p0 < 65535 ? oplanes - p0 : 65535;
         const long in_pl = mode == FDN_RS_PIXEL_UNSHUFFLE ? p0 / (r * r) : p0;
         FDN_CHECK_ARG(mode != FDN_RS_PIXEL_UNSHUFFLE || p0 % (r * r) == 0);
+        const bool quad = OW % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+                          (mode != FDN_RS_BILINEAR_HALF || W % 8 == 0);
+        const dim3 qgrid((unsigned)cdiv((long)OH * (OW / 4), 256), (unsigned)np);
+        if (quad && mode == FDN_RS_BILINEAR_X2)
+            hipLaunchKernelGGL(resample4_kernel<FDN_RS_BILINEAR_X2>, qgrid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                               x + in_pl * H * W, out + p0 * OH * OW, H, W, OH, OW);
+        else if (quad && mode == FDN_RS_BILINEAR_HALF)
+            hipLaunchKernelGGL(resample4_kernel<FDN_RS_BILINEAR_HALF>, qgrid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                               x + in_pl * H * W, out + p0 * OH * OW, H, W, OH, OW);
+        else if (quad && mode == FDN_RS_NEAREST_X2 && W % 2 == 0)
+            hipLaunchKernelGGL(resample4_kernel<FDN_RS_NEAREST_X2>, qgrid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                               x + in_pl * H * W, out + p0 * OH * OW, H, W, OH, OW);
+        else
         hipLaunchKernelGGL(resample_kernel, dim3(cdiv(OW, 256), OH, (unsigned)np), dim3(256), 0, static_cast<hipStream_t>(stream),
                            x + in_pl * H * W, out + p0 * OH * OW, np, H, W, OH, OW, mode, r);
     }

@@ -505,3 +505,20 @@ def test_conv1x1_baseline_shapes_all_forms(A, K, N, H, W):
         st = got._fdn_stats.cpu().view(2, H, W).double()
         assert (st[0] - tot.mean(1)[0]).abs().max() < 1e-5
         assert rel_rms(st[1], 1.0 / torch.sqrt(tot.var(1, unbiased=False)[0] + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("H,W", [(16, 24), (9, 14), (23, 40), (8, 8)])
+def test_resample_bilinear_matches_torch(A, H, W):
+    """Both bilinear modes (quad-per-thread kernels where the width allows, scalar kernel otherwise) against
+    F.interpolate(align_corners=False) in float64: x2 up (FDN_arch.py Upsample) and x0.5 down."""
+    from fdn_hip import ops
+    x = _rnd(2, 3, H, W, seed=H * W)
+    up = ops.resample(dev(x), ops.RS_BILINEAR_X2)
+    ref = torch.nn.functional.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    assert rel_rms(up.cpu(), ref) < 1e-6 and (up.cpu().double() - ref).abs().max() < 1e-5
+    nn_ = ops.resample(dev(x), ops.RS_NEAREST_X2)
+    assert torch.equal(nn_.cpu(), torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest"))
+    if H % 2 == 0 and W % 2 == 0:
+        dn = ops.resample(dev(x), ops.RS_BILINEAR_HALF)
+        refd = torch.nn.functional.interpolate(x.double(), scale_factor=0.5, mode="bilinear", align_corners=False)
+        assert rel_rms(dn.cpu(), refd) < 1e-6
