@@ -275,17 +275,16 @@ __global__ __launch_bounds__(256) void resample4_kernel(const float* __restrict_
 // fourier_fuse.fpre[1]: Conv2d(n, n, 1, padding=1, groups=n): (H+2)x(W+2) map, bias-only border
 __global__ __launch_bounds__(256) void dw1x1_pad1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out, int C, int H,
-                                                         int W, long total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+                                                         int W) {
+    // grid = (column blocks, output rows, planes): no per-element division (cf. resample_kernel)
     const int OW = W + 2, OH = H + 2;
-    const int ox = (int)(idx % OW);
-    const long t = idx / OW;
-    const int oy = (int)(t % OH);
-    const long pl = t / OH;
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    if (ox >= OW) return;
+    const int oy = blockIdx.y;
+    const long pl = blockIdx.z;
     const int c = (int)(pl % C);
     const bool in = oy >= 1 && oy <= H && ox >= 1 && ox <= W;
-    out[idx] = (in ? w[c] * x[pl * H * W + (long)(oy - 1) * W + ox - 1] : 0.f) + bias[c];
+    out[(pl * OH + oy) * OW + ox] = (in ? w[c] * x[pl * H * W + (long)(oy - 1) * W + ox - 1] : 0.f) + bias[c];
 }
 
 // AvgPool2d(3, stride 2, padding 1), count_include_pad=True (LPNet_arch.py:94)
@@ -435,9 +434,9 @@ extern "C" int fdn_resample(const float* x, float* out, long planes, int H, int 
 extern "C" int fdn_dw1x1_pad1(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int W,
                               fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w && bias && out && B > 0 && C > 0 && H > 0 && W > 0);
-    const long total = (long)B * C * (H + 2) * (W + 2);
-    hipLaunchKernelGGL(dw1x1_pad1_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, bias, out,
-                       C, H, W, total);
+    FDN_CHECK_ARG(H + 2 <= 65535 && (long)B * C <= 65535);
+    hipLaunchKernelGGL(dw1x1_pad1_kernel, dim3(cdiv(W + 2, 256), H + 2, (unsigned)(B * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, w, bias, out, C, H, W);
     return fdn_launch_status();
 }
 
