@@ -97,7 +97,7 @@ class FDSA(nn.Module):
             return y
         stats = ops.chan_stats(o[:, :3 * e], groups=3)
         return ops.conv1x1(o[:, :3 * e], _w(self.project_out.weight), ln3_gate=(stats, gam, bet, o[:, 3 * e:]), res=res,
-                           want_stats=res is not None)
+                           want_stats=res is not None, cache=(self._c, "po"))
 
     def forward(self, x):
         return self.fused(x)
@@ -126,7 +126,8 @@ class FDFFN(nn.Module):
         st = ops.block_storage(x.shape[1], x.shape[2] * x.shape[3])      # hidden tensors: fp32, or bf16 storage (levels 1-2 in bf16 mode)
         h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln, cache=(self._c, "pi"), out_dtype=st)
         y = ops.fdffn_mid(h, _w(self.space[0].weight), _w(self.space[2].weight), _w(self.ffta), _w(self.fftp))
-        return ops.ffn_tail(y, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None)
+        return ops.ffn_tail(y, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None,
+                            cache=(self._c, "po"))
 
     def forward(self, x, x_high=None, xp2=None, x_img=None):
         return self.fused(x)
@@ -150,6 +151,7 @@ class FCAFFN(nn.Module):
         self.conv3_mul = nn.Conv2d(hidden, hidden, kernel_size=3, padding=1, groups=hidden, bias=bias)
         self.norm = LayerNorm(hidden)
         self.dwconv = nn.Conv2d(hidden, hidden * 2, kernel_size=3, padding=1, groups=hidden, bias=bias)
+        self._c = _Cache()
 
     def fused(self, xn, x_high, xp2, x_img, res=None, ln=None):
         """xn: the block input (already norm3-normalised), kept as x1 (FDN_arch.py:410).  ln = (stats, gamma, beta): xn is the
@@ -167,8 +169,9 @@ class FCAFFN(nn.Module):
             stats = ops.chan_stats(xi)
             mul, add = ops.img_mod_maps(x_img, _w(self.conv1_mul.weight), _w(self.conv3_mul.weight),
                                         _w(self.conv1_add.weight), _w(self.conv3_add.weight))
-            t = ops.conv1x1(xi, _w(self.project_in.weight), ln_muladd=(stats, gam, bet, xn), muladd=(mul, add))
-        return ops.ffn_tail(t, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None)
+            t = ops.conv1x1(xi, _w(self.project_in.weight), ln_muladd=(stats, gam, bet, xn), muladd=(mul, add), cache=(self._c, "pi"))
+        return ops.ffn_tail(t, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None,
+                            cache=(self._c, "po"))
 
     def forward(self, x, x_high, xp2, x_img=None):
         return self.fused(x, x_high, xp2, x_img)
@@ -222,7 +225,7 @@ class Fuse(nn.Module):
         x = self.att_channel((x, x_high, x_high_p, x_img))[0]
         wf = self._c.get("w", [self.conv2.weight], lambda: self.conv2.weight.detach()[:n] + self.conv2.weight.detach()[n:])
         bf = self._c.get("b", [self.conv2.bias], lambda: self.conv2.bias.detach()[:n] + self.conv2.bias.detach()[n:])
-        return ops.conv1x1(x, wf, bf)
+        return ops.conv1x1(x, wf, bf, cache=(self._c, "c2"))
 
 
 class OverlapPatchEmbed(nn.Module):

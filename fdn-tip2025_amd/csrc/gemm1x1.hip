@@ -1455,6 +1455,8 @@ int launch_pro(const fdn_conv1x1_desc& d, hipStream_t s) {
 
 // gemm_tile.hip: LDS-tiled kernel for the deep N = 128 shapes; FDN_ERR_UNSUPPORTED = not one of them
 int fdn_gemm_tile(const fdn_conv1x1_desc& d, hipStream_t s);
+// gemm_split.hip: the same shapes and the N > 128 ones on the bf16 matrix pipe (split operands), when the caller supplies packed weights
+int fdn_gemm_split(const fdn_conv1x1_desc& d, hipStream_t s);
 
 extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
     FDN_CHECK_ARG(dp != nullptr);
@@ -1512,6 +1514,10 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
             }
         }
         return FDN_ERR_UNSUPPORTED;
+    }
+    {
+        const int rc = fdn_gemm_split(d, s);            // level 3 with packed weights: fp32 on the bf16 matrix pipe (gemm_split.hip)
+        if (rc != FDN_ERR_UNSUPPORTED) return rc;
     }
     {
         const int rc = fdn_gemm_tile(d, s);             // 459 -> 128 (LN3 * v_value), 345 -> 128, 128 -> 128 at level 3

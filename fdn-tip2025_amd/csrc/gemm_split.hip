@@ -1,0 +1,350 @@
+// fp32 1x1-conv GEMM on the bf16 matrix pipe, for the deep level-3 shapes (to_hidden 128 -> 612, FDFFN project_in 128 -> 345 and
+// project_out 345 -> 128, FDSA project_out 459 -> 128 with the 3 x LayerNorm * v_value prologue, FCAFFN / Fuse 128 -> 128;
+// FDN_arch.py:576, :456, :474, :633-639, :421, :685).
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate and shares the vector ALU's datapath, so the
+// level-3 GEMMs sat at 60-77 % "MFMA busy" with nothing left to gain.  v_mfma_f32_32x32x16_bf16 is a pipe of its own at 16x that
+// rate.  An fp32 value splits EXACTLY into three bf16 values by truncation (8 + 8 + 8 significant bits: x = x1 + x2 + x3), so
+//     w x = w1 x1 + (w1 x2 + w2 x1) + (w1 x3 + w2 x2 + w3 x1) + O(2^-24 |w x|)
+// and the six bf16 products, each exact in the fp32 accumulator, reproduce the fp32 product to below one fp32 rounding; the sums
+// are fp32 like the fmaf chain's.  Measured against float64 (tools/micro/split_bf16_mfma.hip): relative RMS error 8.5e-8 / 1.7e-7
+// / 3.5e-7 at K = 32 / 128 / 512 against 1.05e-7 / 1.9e-7 / 4.0e-7 for the fp32 MFMA chain; 8 k of a 32 x 32 tile take 134 ns
+// (split of the activations included) against 270 ns.  This is fp32 arithmetic carried out on bf16 multipliers, not bf16 precision.
+//
+// Layout: a workgroup owns 128 pixels x 128 output channels; K streams through LDS in chunks of 32 (two MFMA k-steps of 16).
+// Activations are loaded as fp32 (thread = pixel, 16 consecutive k), get their prologue, are split and written to LDS as three bf16
+// planes in MFMA operand order ([part][k-step][lane half][pixel] x 16 bytes: every operand read is one conflict-free ds_read_b128).
+// The weights are split once, off line, by fdn_conv1x1_pack into the same order, so staging them is a 16-byte copy.  Waves form a
+// 2 x 2 grid (two pixel strips x two channel tiles each): 24 MFMAs per k-step per wave behind 12 operand reads.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ f32x16 mf(fdn_u32x4 a, fdn_u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int TP = 128, TN = 128, KC = 32;
+constexpr int BLK = 3 * 2 * 2 * 128;          // 16-byte units of one operand chunk: [part][k-step][lane half][row]
+constexpr int TRI_E = 10;                     // LN3_GATE: channels e per chunk (10 triples = 30 k + 2 zero columns)
+
+struct SArgs {
+    fdn_conv1x1_desc d;
+    int tiles_per_img, total_ptiles, ntiles;
+};
+
+// k' (position in the packed K axis) -> source column of w / channel of x.  Natural order, or for LN3_GATE the triple order
+// k' = 32 c + 16 hh + 3 j + g  ->  e = 10 c + 5 hh + j, channel g E + e  (position 15 of each half is a zero column)
+__host__ __device__ __forceinline__ int tri_src(int kp, int E) {
+    const int c = kp >> 5, hh = (kp >> 4) & 1, q = kp & 15;
+    if (q == 15) return -1;
+    const int j = q / 3, g = q - 3 * j, e = TRI_E * c + 5 * hh + j;
+    return e < E ? g * E + e : -1;
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
+    const fdn_conv1x1_desc& d = a.d;
+    constexpr bool TRI = PRO == FDN_PRO_LN3_GATE, LN = PRO == FDN_PRO_LN, LNM = PRO == FDN_PRO_LN_MULADD;
+    __shared__ fdn_u32x4 Xs[BLK];
+    __shared__ fdn_u32x4 Ws[BLK];
+    __shared__ float red[2][TP];
+    const int K = d.K, N = d.N, E = d.ln_group;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, ln = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int nch = TRI ? (E + TRI_E - 1) / TRI_E : (K + KC - 1) / KC;
+
+    // item S = (pixel tile, channel tile), channel tile fastest: the channel tiles of one pixel tile run on the same XCD back to
+    // back and share its activations in L2
+    const unsigned S = xcd_contiguous(blockIdx.x, (unsigned)(a.total_ptiles * a.ntiles));
+    const unsigned pt = S / (unsigned)a.ntiles;
+    const int nt = (int)(S - pt * a.ntiles);
+    const int b = (int)(pt / (unsigned)a.tiles_per_img);
+    const unsigned p0 = (pt - (unsigned)b * a.tiles_per_img) * TP;
+    const int n0 = nt * TN;
+
+    // ---- staging roles: thread = (pixel xp, k-step hh) handles the 16 k of that step; weights: six 16-byte units ----
+    const int xp = tid & (TP - 1), hh = wave >> 1;
+    const unsigned pix = min(p0 + (unsigned)xp, P - 1);
+    const rsrc_t rx = mk_rsrc(d.x[0] + (long)b * d.xbs[0], (unsigned)K * P4);
+    const rsrc_t rv = mk_rsrc((TRI || LNM) ? d.xb + (long)b * d.xbbs : d.x[0], TRI ? (unsigned)E * P4 : LNM ? (unsigned)K * P4 : 0u);
+    const fdn_u32x4* wsrc = reinterpret_cast<const fdn_u32x4*>(d.wpk) + (long)nt * nch * BLK;
+    float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};                  // (x - mean) * rstd = x * sa + sb
+    if (TRI || LN || LNM) {
+#pragma unroll
+        for (int g = 0; g < (TRI ? 3 : 1); ++g) {
+            const float* sp = d.stats + ((long)b * (TRI ? 3 : 1) + g) * 2 * P;
+            sa[g] = sp[P + pix];
+            sb[g] = -sp[pix] * sa[g];
+        }
+    }
+    float xv[16], vv[(TRI || LNM) ? (TRI ? 5 : 16) : 1];
+    float ga[(TRI || LNM) ? 16 : 1], be[(TRI || LNM) ? 16 : 1];
+    fdn_u32x4 wv[6];
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+        if constexpr (TRI) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int e = c * TRI_E + 5 * hh + j;                         // wave-uniform; e >= E: outside the descriptors, reads 0
+                vv[j] = e < E ? bload(rv, pix * 4u, (unsigned)e * P4) : 0.f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    xv[3 * j + g] = e < E ? bload(rx, pix * 4u, (unsigned)(g * E + e) * P4) : 0.f;
+                    ga[3 * j + g] = e < E ? d.gamma[g * E + e] : 0.f;
+                    be[3 * j + g] = e < E ? d.beta[g * E + e] : 0.f;
+                }
+            }
+        } else {
+            const int k0 = c * KC + 16 * hh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                xv[i] = bload(rx, pix * 4u, (unsigned)(k0 + i) * P4);         // k >= K reads 0
+                if constexpr (LNM) {
+                    vv[i] = bload(rv, pix * 4u, (unsigned)(k0 + i) * P4);
+                    ga[i] = k0 + i < K ? d.gamma[k0 + i] : 0.f;
+                    be[i] = k0 + i < K ? d.beta[k0 + i] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wv[i] = wsrc[(long)c * BLK + tid + 256 * i];
+    };
+    auto stash = [&](int c) __attribute__((always_inline)) {
+        float v[16];
+        if constexpr (TRI) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    v[3 * j + g] = fmaf(fmaf(xv[3 * j + g], sa[g], sb[g]), ga[3 * j + g], be[3 * j + g]) * vv[j];   // FDN_arch.py:633-638 (e >= E: ga = be = 0)
+            v[15] = 0.f;
+        } else {
+            const int k0 = c * KC + 16 * hh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if constexpr (LN) v[i] = k0 + i < K ? fmaf(xv[i], sa[0], sb[0]) : 0.f;       // affine part folded into the weights
+                else if constexpr (LNM) v[i] = fmaf(fmaf(fmaf(xv[i], sa[0], sb[0]), ga[i], be[i]), vv[i], vv[i]);     // norm(x) * x1 + x1, FDN_arch.py:420
+                else v[i] = xv[i];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fdn_u32x4 p1, p2, p3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[8 * h + 2 * j], x1 = v[8 * h + 2 * j + 1];
+                p1[j] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+                const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+                p2[j] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+                p3[j] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+            }
+            Xs[((0 * 2 + hh) * 2 + h) * 128 + xp] = p1;
+            Xs[((1 * 2 + hh) * 2 + h) * 128 + xp] = p2;
+            Xs[((2 * 2 + hh) * 2 + h) * 128 + xp] = p3;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Ws[tid + 256 * i] = wv[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][t][r] = 0.f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const fdn_u32x4* xb_ = Xs + kh * 128 + wi * 64 + ln;
+    const fdn_u32x4* wb_ = Ws + kh * 128 + wj * 64 + ln;
+    for (int c = 0; c < nch; ++c) {
+        const bool more = c + 1 < nch;
+        if (more) fetch(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fdn_u32x4 A[2][3], B[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    B[s][p] = xb_[((p * 2 + ks) * 2) * 128 + s * 32];
+                    A[s][p] = wb_[((p * 2 + ks) * 2) * 128 + s * 32];
+                }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {                                 // small terms first
+                    acc[s][t] = mf(A[t][2], B[s][0], acc[s][t]);
+                    acc[s][t] = mf(A[t][1], B[s][1], acc[s][t]);
+                    acc[s][t] = mf(A[t][0], B[s][2], acc[s][t]);
+                    acc[s][t] = mf(A[t][1], B[s][0], acc[s][t]);
+                    acc[s][t] = mf(A[t][0], B[s][1], acc[s][t]);
+                    acc[s][t] = mf(A[t][0], B[s][0], acc[s][t]);
+                }
+        }
+        __syncthreads();                      // every wave has read this chunk
+        if (more) stash(c + 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual | mul-add, store; LayerNorm statistics of the result (one channel tile only) ----
+    const int Nt = min(N - n0, TN);           // channels of this tile
+    const rsrc_t ro = mk_rsrc(d.out + (long)b * d.obs + (long)n0 * P, (unsigned)Nt * P4);
+    const bool RES = d.epi == FDN_EPI_RES, MA = d.epi == FDN_EPI_MULADD;
+    const rsrc_t rr = mk_rsrc(RES ? d.res + (long)b * d.rbs + (long)n0 * P : MA ? d.mul + (long)b * d.mbs + (long)n0 * P : d.out, (RES || MA) ? (unsigned)Nt * P4 : 0u);
+    const rsrc_t ra = mk_rsrc(MA ? d.add + (long)b * d.mbs + (long)n0 * P : d.out, MA ? (unsigned)Nt * P4 : 0u);
+    float psum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned p = p0 + (unsigned)(wi * 64 + s * 32 + ln);
+        const unsigned voff = p < P ? (4u * kh * P + p) * 4u : 0x80000000u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float rv_[16], av_[16];
+            if (RES || MA) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv_[r] = bload(rr, voff, (unsigned)((wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2)) * P4);
+            }
+            if (MA) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av_[r] = bload(ra, voff, (unsigned)((wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2)) * P4);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = (wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2);      // + 4 kh per lane
+                float v = acc[s][t][r];
+                if (d.bias) v += (nrow + 4 * kh < Nt) ? d.bias[n0 + nrow + 4 * kh] : 0.f;
+                if (RES) v += rv_[r];
+                if (MA) v = fmaf(v, rv_[r], av_[r]);
+                bstore(v, ro, voff, (unsigned)nrow * P4);                         // rows >= Nt fall outside the descriptor
+                v = (nrow + 4 * kh < Nt) ? v : 0.f;
+                acc[s][t][r] = v;
+                psum[s] += v;
+            }
+        }
+    }
+    if (d.stats_out) {
+        // two-pass mean / variance: the two waves of a pixel strip pair (wj = 0, 1) hold complementary channel halves
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            psum[s] += __shfl_xor(psum[s], 32);
+            if (kh == 0) red[wj][wi * 64 + s * 32 + ln] = psum[s];
+        }
+        __syncthreads();
+        float mean[2], q[2] = {0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int pl = wi * 64 + s * 32 + ln;
+            mean[s] = (red[0][pl] + red[1][pl]) / (float)N;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nrow = (wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const float dl = acc[s][t][r] - mean[s];
+                    q[s] += nrow < N ? dl * dl : 0.f;
+                }
+            q[s] += __shfl_xor(q[s], 32);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (kh == 0) red[wj][wi * 64 + s * 32 + ln] = q[s];
+        __syncthreads();
+        if (wj == 0 && kh == 0) {
+            float* sp = d.stats_out + (long)b * 2 * P;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int pl = wi * 64 + s * 32 + ln;
+                const unsigned p = p0 + (unsigned)pl;
+                if (p < P) {
+                    sp[p] = mean[s];
+                    sp[P + p] = 1.0f / sqrtf((red[0][pl] + red[1][pl]) / (float)N + 1e-5f);
+                }
+            }
+        }
+    }
+}
+
+template <int PRO>
+int launch_split(const fdn_conv1x1_desc& d, hipStream_t s) {
+    SArgs a;
+    a.d = d;
+    a.tiles_per_img = cdiv(d.P, TP);
+    a.total_ptiles = d.B * a.tiles_per_img;
+    a.ntiles = cdiv(d.N, TN);
+    hipLaunchKernelGGL(gemm_split_kernel<PRO>, dim3((unsigned)(a.total_ptiles * a.ntiles)), dim3(256), 0, s, a);
+    return fdn_launch_status();
+}
+
+// one thread per 16-byte unit of the packed weights: 8 consecutive k' of one output row, one of the three bf16 parts
+__global__ void pack_split_kernel(const float* __restrict__ w, fdn_u32x4* __restrict__ out, int N, int K, int E, int nch, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = (int)(i & 127), h = (int)((i >> 7) & 1), ks = (int)((i >> 8) & 1);
+    const long q = i >> 9;
+    const int part = (int)(q % 3), c = (int)((q / 3) % nch), nt = (int)(q / 3 / nch);
+    const int row = nt * TN + n;
+    fdn_u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kp = c * KC + ks * 16 + h * 8 + 2 * j + u;
+            const int k = E > 0 ? tri_src(kp, E) : (kp < K ? kp : -1);
+            float x = (row < N && k >= 0) ? w[(long)row * K + k] : 0.f;
+            for (int p = 0; p < part; ++p) x -= __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+            v[u] = x;
+        }
+        o[j] = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
+    }
+    out[i] = o;
+}
+
+}  // namespace
+
+// FDN_ERR_UNSUPPORTED = not a shape of this kernel (fdn_conv1x1 then picks another)
+int fdn_gemm_split(const fdn_conv1x1_desc& d, hipStream_t s) {
+    if (!d.wpk || d.K < 96 || d.N < 96 || d.kseg[1] > 0 || d.kseg[2] > 0 || d.act != FDN_ACT_NONE || d.x_bf16 || d.out_bf16) return FDN_ERR_UNSUPPORTED;
+    if (d.stats_out && d.N > TN) return FDN_ERR_UNSUPPORTED;
+    if ((long)d.B * cdiv(d.P, TP) * cdiv(d.N, TN) > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
+    switch (d.pro) {
+        case FDN_PRO_NONE: return launch_split<FDN_PRO_NONE>(d, s);
+        case FDN_PRO_LN: return launch_split<FDN_PRO_LN>(d, s);
+        case FDN_PRO_LN3_GATE: return launch_split<FDN_PRO_LN3_GATE>(d, s);
+        case FDN_PRO_LN_MULADD: return launch_split<FDN_PRO_LN_MULADD>(d, s);
+    }
+    return FDN_ERR_UNSUPPORTED;
+}
+
+extern "C" long fdn_conv1x1_pack_bytes(int N, int K, int ln3_E) {
+    const long nch = ln3_E > 0 ? (ln3_E + TRI_E - 1) / TRI_E : (K + KC - 1) / KC;
+    return (long)cdiv(N, TN) * nch * BLK * 16;
+}
+
+extern "C" int fdn_conv1x1_pack(const float* w, int N, int K, int ln3_E, void* wpk, fdn_stream_t stream) {
+    FDN_CHECK_ARG(w && wpk && N > 0 && K > 0 && (ln3_E == 0 || 3 * ln3_E == K));
+    const int nch = ln3_E > 0 ? (ln3_E + TRI_E - 1) / TRI_E : (K + KC - 1) / KC;
+    const long total = (long)cdiv(N, TN) * nch * BLK;
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       static_cast<fdn_u32x4*>(wpk), N, K, ln3_E, nch, total);
+    return fdn_launch_status();
+}

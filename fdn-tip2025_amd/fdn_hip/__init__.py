@@ -29,7 +29,7 @@ class Conv1x1Desc(ctypes.Structure):
         ("stats", c_fp), ("gamma", c_fp), ("beta", c_fp), ("xb", c_fp), ("xbbs", ctypes.c_long),
         ("act", ctypes.c_int), ("epi", ctypes.c_int),
         ("res", c_fp), ("rbs", ctypes.c_long), ("mul", c_fp), ("add", c_fp), ("mbs", ctypes.c_long),
-        ("vec4", ctypes.c_int), ("stats_out", c_fp), ("x_bf16", ctypes.c_int), ("out_bf16", ctypes.c_int),
+        ("vec4", ctypes.c_int), ("stats_out", c_fp), ("x_bf16", ctypes.c_int), ("out_bf16", ctypes.c_int), ("wpk", c_fp),
     ]
 
 
@@ -37,7 +37,7 @@ class FdnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 7          # include/fdn_hip.h: bumped on any signature change
+ABI_VERSION = 8          # include/fdn_hip.h: bumped on any signature change
 
 
 def lib_path():
@@ -67,7 +67,7 @@ def _declare(l):
     kinds = {"P": ctypes.c_void_p, "I": ctypes.c_int, "L": ctypes.c_long, "F": ctypes.c_float, "DESC": ctypes.POINTER(Conv1x1Desc)}
     for name, (ret, sig) in PROTOTYPES.items():
         f = getattr(l, name)                       # AttributeError: the library lacks a symbol the header declares
-        f.restype = ctypes.c_char_p if ret == "S" else ctypes.c_int
+        f.restype = ctypes.c_char_p if ret == "S" else ctypes.c_long if ret == "L" else ctypes.c_int
         f.argtypes = [kinds[k] for k in sig]
 
 

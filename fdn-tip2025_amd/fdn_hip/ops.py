@@ -91,6 +91,15 @@ def fold_ln(w, bias, gamma, beta):
     return wf, bf.contiguous()
 
 
+def conv1x1_pack(w, ln3_E=0):
+    """w [N, K(,1,1)] -> the split-bf16 operand image of fdn_conv1x1_pack (gemm_split.hip): three exact bf16 parts per weight."""
+    N = w.shape[0]
+    K = w.numel() // N
+    wpk = torch.empty(lib().fdn_conv1x1_pack_bytes(N, K, ln3_E), device=w.device, dtype=torch.uint8)
+    check(lib().fdn_conv1x1_pack(_flat(w.reshape(N, K), "w"), N, K, ln3_E, ctypes.c_void_p(wpk.data_ptr()), stream()), "fdn_conv1x1_pack")
+    return wpk
+
+
 def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None, ln_muladd=None, res=None,
             muladd=None, want_stats=False, cache=None, out_dtype=torch.float32):
     """1x1 conv with fused prologue/epilogue (fdn_conv1x1).
@@ -101,7 +110,9 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
     xs: tensor or list of <=3 tensors concatenated along channels.  w: [N, K] or [N, K, 1, 1].
     ln=(stats, gamma, beta) | ln3_gate=(stats, gamma[3E], beta[3E], vv) | ln_muladd=(stats, gamma, beta, x1)
     res: residual added after act | muladd=(mul, add).
-    cache=(WeightCache, name): where the LayerNorm-folded operands of `ln` are kept (else they are rebuilt per call).
+    cache=(WeightCache, name): where the derived operands are kept - the LayerNorm-folded weights of `ln` (else they are rebuilt
+    per call) and, for the deep shapes (K, N >= 96: level 3), the packed split-bf16 weights that put the GEMM on the bf16
+    matrix pipe (without a cache those shapes run the fp32-MFMA kernels).
     out_dtype=torch.bfloat16 stores the result as bf16 (FDFFN project_in); a bf16 `xs` is read as bf16 storage
     (FDFFN project_out).  The library refuses forms it has no bf16 kernel for.
     """
@@ -125,6 +136,7 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
     d.out, d.obs = _planes(out, "out", bf16_ok=True)
     d.B, d.K, d.N, d.P = B, K, N, P
     d.pro, d.ln_group = PRO_NONE, K
+    w0, bias0 = w, bias
     if ln is not None:
         d.pro = PRO_LN                        # the kernel normalises only; the affine part rides in the weights
         if cache is not None:
@@ -141,6 +153,11 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
         d.pro = PRO_LN_MULADD
         d.stats, d.gamma, d.beta = _flat(ln_muladd[0], "stats"), _flat(ln_muladd[1], "gamma"), _flat(ln_muladd[2], "beta")
         d.xb, d.xbbs = _planes(ln_muladd[3], "x1")
+    if (cache is not None and K >= 96 and N >= 96 and len(xs) == 1 and act == ACT_NONE and xs[0].dtype == torch.float32
+            and out.dtype == torch.float32):
+        srcs = [w0, bias0] + (list(ln[1:3]) if ln is not None else [])
+        d.wpk = ctypes.c_void_p(cache[0].get(cache[1] + ":pk", srcs, lambda w=w: conv1x1_pack(
+            w, K // 3 if ln3_gate is not None else 0)).data_ptr())
     d.act = act
     d.epi = EPI_NONE
     if res is not None:
@@ -252,7 +269,7 @@ def fdffn_mid(x, w0, w2, ffta, fftp, out_dtype=None):
 FFN_TAIL_MODE = None          # None = per-shape choice below; "sw" | "fused" | "split" forces one (A/B runs, tests)
 
 
-def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None):
+def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None, cache=None):
     """gate + project_out + residual (+ next LayerNorm statistics).
       "sw"    one launch, sliding-window kernel (fdn_ffn_tail form 1): N <= 64, W % 4 == 0, fp32 or bf16-storage y;
       "fused" one launch, the chunked kernel of round 1 (fdn_ffn_tail form 0), fp32 y;
@@ -267,7 +284,7 @@ def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None):
         mode = "sw" if (W % 4 == 0 and (N <= 32 or (N <= 64 and C <= 64))) else "split"
     if mode == "split":
         g = dwconv_gate(y, dw_w)                 # (bf16 storage in -> bf16 storage out -> the project_out conv reads bf16)
-        return conv1x1(g, w, res=res, want_stats=want_stats)
+        return conv1x1(g, w, res=res, want_stats=want_stats, cache=cache)
     out = torch.empty((B, N, H, W), device=y.device, dtype=torch.float32)
     stats = torch.empty((B, 1, 2, H * W), device=y.device, dtype=torch.float32) if want_stats else None
     check(lib().fdn_ffn_tail(_flat(y, "y", True), _flat(dw_w, "dw_w"), _flat(w, "w"), _flat(res, "res"), _flat(out, "out"),

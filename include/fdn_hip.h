@@ -80,8 +80,21 @@ typedef struct fdn_conv1x1_desc {
                          the LayerNorm statistics the NEXT block needs, produced in this epilogue */
     int x_bf16;       /* x[0] is stored as bf16 (xbs in elements): FDFFN project_out forms only, else FDN_ERR_UNSUPPORTED */
     int out_bf16;     /* out is stored as bf16 (obs in elements): FDFFN project_in forms only (K <= 64, N >= 2K) */
+    const void* wpk;  /* optional: `w` as packed by fdn_conv1x1_pack (same N, K; ln3_E = ln_group for FDN_PRO_LN3_GATE, else 0).
+                         Deep shapes (K >= 96, N >= 96, one x segment, no activation, fp32 storage) then run on the split-bf16
+                         kernel; every other shape ignores it.  `w` must still be given. */
 } fdn_conv1x1_desc;
 int fdn_conv1x1(const fdn_conv1x1_desc* d, fdn_stream_t stream);
+
+/* Weights of a 1x1 conv split for the bf16 matrix pipe (gemm_split.hip): every fp32 weight is cut EXACTLY into three bf16 parts
+ * (w = w1 + w2 + w3 by truncation) and laid out in MFMA operand order per (128-channel tile, 32-deep K chunk).  The kernel splits
+ * the activations the same way and accumulates the six leading products in fp32: fp32 arithmetic to below one rounding, at the
+ * bf16 matrix rate (the fp32 MFMA runs at the vector rate).  Replaces nothing in the reference: it is F.conv2d's weight operand
+ * (FDN_arch.py:576, :456, :474, :639) in the form the kernel wants, built once per weight.
+ * w [N][K] fp32 (LayerNorm affine part already folded in for FDN_PRO_LN); ln3_E = E for the FDN_PRO_LN3_GATE order (K = 3E),
+ * else 0; wpk: fdn_conv1x1_pack_bytes(N, K, ln3_E) bytes. */
+long fdn_conv1x1_pack_bytes(int N, int K, int ln3_E);
+int fdn_conv1x1_pack(const float* w, int N, int K, int ln3_E, void* wpk, fdn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Channel LayerNorm pieces (WithBias_LayerNorm over the channel axis, FDN_arch.py:313-342).

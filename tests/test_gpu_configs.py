@@ -1,0 +1,129 @@
+"""The BASELINE.json configurations themselves, end to end on the HIP path.
+
+* configs[0]  one 256 x 256 crop through the inference_fdn_lolblur.py plumbing (LPNet_lolblur.pth -> ratio -> FDN): against the
+              reference's own outputs (tests/golden/make_golden_configs.py, fixture fdn_tamed_256).
+* configs[1]  the 720p frame reflect-padded to 736 x 1280: against the reference's own forward on that frame - 64 seeded windows
+              of each of the four outputs plus whole-tensor moments (fixture fdn_tamed_736x1280).  A wrong level-2 / level-3 stage
+              hook-up that only shows at the planned-FFT shapes fails here.
+* configs[2]  1088 x 1920 in bf16-storage mode: FDSA / FDFFN blocks against the fp32 oracle at that size with the bf16 bound of
+              tests/test_gpu_bf16.py, the whole net at B = 4 for determinism and batch independence.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fdn_oracle as O
+from common import GOLDEN, fdn_weights, fixture, fixture_weights, lpnet_weights, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a ROCm GPU")
+    import fdn_hip
+    fdn_hip.lib()
+    from basicsr.models.archs import FDN_arch
+    yield FDN_arch
+    fdn_hip.set_storage_dtype("f32")
+
+
+@pytest.fixture(autouse=True)
+def _fp32_after():
+    yield
+    import fdn_hip
+    fdn_hip.set_storage_dtype("f32")
+
+
+def dev(t):
+    return t.to("cuda:0").contiguous()
+
+
+def load(mod, sd):
+    mod.load_state_dict(sd, strict=True)
+    return mod.to("cuda:0").eval()
+
+
+def _nets(A, tame):
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    return load(A.FDN(), fdn_weights(tame=tame)), load(I_predict_net(), lpnet_weights())
+
+
+def test_config0_256_crop_matches_reference(A):
+    z = np.load(os.path.join(GOLDEN, "fdn_tamed_256.npz"))
+    net, lp = _nets(A, float(z["tame"]))
+    x = dev(torch.from_numpy(z["x"]))
+    with torch.no_grad():
+        ratio = lp(x)
+        outs = net(x, ratio_i=ratio, device=torch.device("cuda:0"))
+    assert torch.allclose(ratio.cpu(), torch.from_numpy(z["ratio"]), rtol=0, atol=5e-6)
+    for got, key in zip(outs, ("y", "q1", "q2", "q3")):
+        p = O.psnr(got.cpu(), torch.from_numpy(z[key]))
+        assert p > 100.0, f"fdn_tamed_256.{key}: PSNR {p:.1f} dB against the reference's output"
+
+
+def test_config1_736x1280_frame_matches_reference(A):
+    """The reference's forward on the padded 720p frame (it takes ~6 minutes on the CPU; stored as windows + moments)."""
+    z = np.load(os.path.join(GOLDEN, "fdn_tamed_736x1280.npz"))
+    net, lp = _nets(A, float(z["tame"]))
+    x = torch.rand(1, 3, 720, 1280, generator=torch.Generator().manual_seed(int(z["x_seed"])))
+    x = torch.nn.functional.pad(x, (0, 0, 0, 16), mode="reflect")                 # inference_fdn_lolblur.py:60-63
+    assert abs(x.double().sum().item() - float(z["x_sum64"])) < 1e-6, "the seeded input is not the one the fixture was made from"
+    with torch.no_grad():
+        ratio = lp(dev(x))
+        outs = net(dev(x), ratio_i=ratio, device=torch.device("cuda:0"))
+    assert torch.allclose(ratio.cpu(), torch.from_numpy(z["ratio"]), rtol=0, atol=5e-6)
+    for got, key, size in zip(outs, ("y", "q1", "q2", "q3"), (32, 32, 16, 8)):
+        got = got.cpu()
+        org, win, mom = z[key + "_org"], torch.from_numpy(z[key + "_win"]), torch.from_numpy(z[key + "_mom"])
+        mine = torch.stack([got[0, :, y0:y0 + size, x0:x0 + size] for y0, x0 in org.tolist()])
+        p = O.psnr(mine, win)
+        assert p > 100.0, f"736x1280 {key}: windows PSNR {p:.1f} dB against the reference's output"
+        d = got.double()
+        m = torch.stack([d.sum((0, 2, 3)), (d * d).sum((0, 2, 3))])
+        n = got.shape[2] * got.shape[3]
+        assert ((m[0] - mom[0]).abs() / n).max() < 1e-6, f"{key}: per-channel mean off by {((m[0] - mom[0]).abs() / n).max():.2e}"
+        assert ((m[1] - mom[1]).abs() / mom[1]).max() < 1e-6, f"{key}: per-channel energy off"
+
+
+BLOCK_REL_RMS = 6e-3          # tests/test_gpu_bf16.py: one block in bf16-storage mode against fp32
+
+
+@pytest.mark.parametrize("name,cls,fn", [("fdsa_c32", "FDSA", "fdsa"), ("fdffn_c32", "FDFFN", "fdffn")])
+def test_config2_1080p_bf16_blocks_vs_oracle(A, name, cls, fn):
+    """Level-1 blocks at 1088 x 1920 in bf16-storage mode (the pixel-pair bf16 load / store forms at W = 1920) against the
+    fp32 CPU oracle at that size."""
+    import fdn_hip
+    sd = fixture_weights(name, fixture(name)["shapes"])
+    m = load(getattr(A, cls)(32), sd)
+    x = torch.randn(1, 32, 1088, 1920, generator=torch.Generator().manual_seed(19))
+    with torch.no_grad():
+        ref = getattr(O, fn)(x, {"." + k: v for k, v in sd.items()}, "")
+        f32 = m(dev(x)).cpu()
+        fdn_hip.set_storage_dtype("bf16")
+        got = m(dev(x)).cpu()
+    e32, e16 = rel_rms(f32, ref), rel_rms(got, ref)
+    print(f"1088x1920 {name}: relative RMS error fp32 {e32:.2e}, bf16 storage {e16:.2e}")
+    assert e32 < 2e-4 and e16 < BLOCK_REL_RMS, (e32, e16)
+
+
+def test_config2_1080p_bf16_whole_net_batch4(A):
+    """configs[2] as the bench runs it (B = 4, 1088 x 1920, bf16 storage): finite, deterministic, batch independent, and within
+    the bf16 end-to-end bound of the fp32 run of the same frame."""
+    import fdn_hip
+    net, lp = _nets(A, 0.03)
+    x = dev(torch.rand(4, 3, 1088, 1920, generator=torch.Generator().manual_seed(23)))
+    with torch.no_grad():
+        ratio = lp(x)
+        f32 = net(x[2:3].contiguous(), ratio_i=ratio[2:3].contiguous())[0]
+        fdn_hip.set_storage_dtype("bf16")
+        a = net(x, ratio_i=ratio)[0]
+        b = net(x, ratio_i=ratio)[0]
+        one = net(x[2:3].contiguous(), ratio_i=ratio[2:3].contiguous())[0]
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a[2:3], one)
+    p = O.psnr(one.cpu(), f32.cpu())
+    print(f"1088x1920 whole net, bf16 storage against fp32 on the HIP path: PSNR {p:.1f} dB")
+    assert p > 55.0, p

@@ -269,12 +269,73 @@ def test_conv1x1_variants(A, K, N, H, W, pro):
     else:
         xin, xs = xd, dev(x)
     ref = torch.nn.functional.conv2d(xin, w.double().view(N, K, 1, 1)) + res.double()
-    got = ops.conv1x1(xs, dev(w), res=dev(res), want_stats=True, **kw)
-    assert rel_rms(got.cpu(), ref) < 2e-6
-    mu, var = ref.mean(1), ref.var(1, unbiased=False)
-    st = got._fdn_stats.cpu().view(B, 2, H, W)
-    tol = 1e-5 if N <= 160 else 1e-4          # N > 160: statistics come from the one-pass fdn_chan_stats kernel
-    assert rel_rms(st[:, 0], mu) < tol and rel_rms(st[:, 1], 1 / torch.sqrt(var + 1e-5)) < tol
+    # without a weight cache: the fp32-MFMA kernels; with one: deep shapes (K, N >= 96) take the split-bf16 kernel (gemm_split.hip)
+    for cache in (None, (ops.WeightCache(), "t")):
+        got = ops.conv1x1(xs, dev(w), res=dev(res), want_stats=True, cache=cache, **kw)
+        assert rel_rms(got.cpu(), ref) < 2e-6, cache
+        mu, var = ref.mean(1), ref.var(1, unbiased=False)
+        st = got._fdn_stats.cpu().view(B, 2, H, W)
+        tol = 1e-5 if N <= 160 else 1e-4          # N > 160: statistics come from the one-pass fdn_chan_stats kernel
+        assert rel_rms(st[:, 0], mu) < tol and rel_rms(st[:, 1], 1 / torch.sqrt(var + 1e-5)) < tol, cache
+
+
+@pytest.mark.parametrize("K,N,H,W,pro,epi", [(128, 612, 23, 40, "ln", "none"), (128, 345, 184, 320, "ln", "none"), (459, 128, 23, 41, "ln3", "res"),
+                                            (345, 128, 184, 320, "none", "res"), (128, 128, 23, 40, "muladd", "muladd"), (96, 96, 5, 7, "none", "bias"),
+                                            (100, 130, 9, 13, "ln", "res"), (345, 128, 8, 17, "ln3", "none"), (128, 128, 184, 320, "muladd", "muladd")])
+def test_conv1x1_split_bf16_kernel(A, K, N, H, W, pro, epi):
+    """gemm_split.hip (fp32 GEMM as six bf16 products of exactly split operands) against fp64, every prologue and epilogue,
+    ragged K / N / pixel tails, the level-3 shapes of config 2: held to the bounds of the fp32-MFMA kernels (2e-6 relative RMS),
+    and it must not be further from fp64 than those kernels by more than rounding noise."""
+    import fdn_hip
+    from fdn_hip import ops
+    B = 2
+    x, w = _rnd(B, K, H, W, seed=1) * 1.5 + 0.3, _rnd(N, K, seed=2) / K ** 0.5
+    xd = x.double()
+    kw, xs = {}, dev(x)
+    if pro == "ln":
+        g, b = _rnd(K, seed=4), _rnd(K, seed=5)
+        xin = O.ln_chan(xd, g.double(), b.double())
+        kw["ln"] = (ops.chan_stats(xs), dev(g), dev(b))
+    elif pro == "ln3":
+        E = K // 3
+        g, b, vv = _rnd(K, seed=4), _rnd(K, seed=5), _rnd(B, E, H, W, seed=6)
+        xin = torch.cat([O.ln_chan(xd[:, i * E:(i + 1) * E], g[i * E:(i + 1) * E].double(), b[i * E:(i + 1) * E].double()) * vv.double()
+                         for i in range(3)], 1)
+        full = dev(torch.cat([x, vv], 1))
+        xs = full[:, :K]
+        kw["ln3_gate"] = (ops.chan_stats(xs, groups=3), dev(g), dev(b), full[:, K:])
+    elif pro == "muladd":
+        g, b, x1 = _rnd(K, seed=4), _rnd(K, seed=5), _rnd(B, K, H, W, seed=6)
+        xin = O.ln_chan(xd, g.double(), b.double()) * x1.double() + x1.double()
+        kw["ln_muladd"] = (ops.chan_stats(xs), dev(g), dev(b), dev(x1))
+    else:
+        xin = xd
+    ref = torch.nn.functional.conv2d(xin, w.double().view(N, K, 1, 1))
+    bias = None
+    if epi == "res":
+        r = _rnd(B, N, H, W, seed=7)
+        ref = ref + r.double()
+        kw["res"] = dev(r)
+    elif epi == "muladd":
+        m, a = _rnd(B, N, H, W, seed=7), _rnd(B, N, H, W, seed=8)
+        ref = ref * m.double() + a.double()
+        kw["muladd"] = (dev(m), dev(a))
+    elif epi == "bias":
+        bias = _rnd(N, seed=9)
+        ref = ref + bias.double().view(1, -1, 1, 1)
+    want_stats = N <= 128
+    wc = ops.WeightCache()
+    got = ops.conv1x1(xs, dev(w), None if bias is None else dev(bias), want_stats=want_stats, cache=(wc, "t"), **kw)
+    assert any(k.endswith(":pk") for k in wc._store), "the packed-weight path was not taken"
+    plain = ops.conv1x1(xs, dev(w), None if bias is None else dev(bias), want_stats=want_stats, **kw)
+    e_split, e_f32 = rel_rms(got.cpu(), ref), rel_rms(plain.cpu(), ref)
+    assert e_split < 2e-6 and e_split < 1.5 * e_f32 + 2e-8, (e_split, e_f32)
+    if want_stats:
+        st = got._fdn_stats.cpu().view(B, 2, H, W)
+        assert rel_rms(st[:, 0], ref.mean(1)) < 1e-5 and rel_rms(st[:, 1], 1 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5)) < 1e-5
+    # bit-exact determinism and batch independence of the tiled launch
+    again = ops.conv1x1(xs, dev(w), None if bias is None else dev(bias), cache=(wc, "t"), **kw)
+    assert torch.equal(again, got)
 
 
 @pytest.mark.parametrize("C,N,H,W", [(86, 32, 24, 40), (345, 128, 16, 24), (64, 64, 46, 40), (43, 16, 8, 35), (172, 64, 40, 72),

@@ -113,6 +113,20 @@ def test_fdn_end_to_end_tamed(name):
         assert p > floor, f"{name}.{key}: PSNR {p:.1f} dB"
 
 
+def test_config0_256_crop():
+    """BASELINE.json configs[0]: the oracle on the 256 x 256 crop against the reference's own outputs (LPNet_lolblur.pth ratio,
+    tamed FDN weights; tests/golden/make_golden_configs.py)."""
+    from common import lpnet_weights
+    fx = fixture("fdn_tamed_256")
+    with torch.no_grad():
+        ratio = O.lpnet_forward(lpnet_weights(), fx["x"])
+        out = O.fdn_forward(fdn_weights(tame=float(fx["tame"])), fx["x"], ratio)
+    assert torch.allclose(ratio, fx["ratio"], rtol=0, atol=2e-6)
+    for got, key in zip(out, ("y", "q1", "q2", "q3")):
+        p = O.psnr(got, fx[key])
+        assert p > 100.0, f"fdn_tamed_256.{key}: PSNR {p:.1f} dB"
+
+
 def test_harness_u8():
     fx = fixture("harness_u8")
     img = fx["img"].numpy()
