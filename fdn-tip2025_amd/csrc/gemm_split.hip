@@ -38,6 +38,7 @@ __device__ __forceinline__ f32x16 mf(fdn_u32x4 a, fdn_u32x4 b, f32x16 c) {
 
 constexpr int TP = 128, TN = 128, KC = 32;
 constexpr int BLK = 3 * 2 * 2 * 128;          // 16-byte units of one operand chunk: [part][k-step][lane half][row]
+constexpr int STRIP_MAX_N = 1024;             // widest output of the strip kernel (its bias lives in LDS)
 constexpr int TRI_E = 10;                     // LN3_GATE: channels e per chunk (10 triples = 30 k + 2 zero columns)
 
 struct SArgs {
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
     const bool RES = d.epi == FDN_EPI_RES, MA = d.epi == FDN_EPI_MULADD;
     const rsrc_t rr = mk_rsrc(RES ? d.res + (long)b * d.rbs + (long)n0 * P : MA ? d.mul + (long)b * d.mbs + (long)n0 * P : d.out, (RES || MA) ? (unsigned)Nt * P4 : 0u);
     const rsrc_t ra = mk_rsrc(MA ? d.add + (long)b * d.mbs + (long)n0 * P : d.out, MA ? (unsigned)Nt * P4 : 0u);
+    const rsrc_t rbias = mk_rsrc(d.bias ? d.bias + n0 : d.w, d.bias ? (unsigned)Nt * 4u : 0u);     // no bias: empty descriptor, reads 0
     float psum[2] = {0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -217,7 +219,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
         const unsigned voff = p < P ? (4u * kh * P + p) * 4u : 0x80000000u;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            float rv_[16], av_[16];
+            float rv_[16], av_[16], bi_[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bi_[r] = bload(rbias, (unsigned)(4 * kh) * 4u, (unsigned)((wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
             if (RES || MA) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv_[r] = bload(rr, voff, (unsigned)((wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2)) * P4);
@@ -229,8 +233,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nrow = (wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2);      // + 4 kh per lane
-                float v = acc[s][t][r];
-                if (d.bias) v += (nrow + 4 * kh < Nt) ? d.bias[n0 + nrow + 4 * kh] : 0.f;
+                float v = acc[s][t][r] + bi_[r];
                 if (RES) v += rv_[r];
                 if (MA) v = fmaf(v, rv_[r], av_[r]);
                 bstore(v, ro, voff, (unsigned)nrow * P4);                         // rows >= Nt fall outside the descriptor
@@ -294,6 +297,126 @@ int launch_split(const fdn_conv1x1_desc& d, hipStream_t s) {
     return fdn_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Short K, many output channels (to_hidden 128 -> 612, FDFFN project_in 128 -> 345; FDN_arch.py:576, :456): a K loop of four chunks
+// cannot cover its own fill and drain (the tiled kernel above ran these at 25 % of the matrix rate).  Here the ACTIVATIONS stay put:
+// a wave loads its 32-pixel strip over all K once, normalises and splits it, and keeps the three bf16 parts in registers as MFMA
+// B operands (K = 128: 96 registers); the weights stream past it through LDS in 32-channel tiles (24 KB, double buffered, one
+// barrier per tile), 6 K/16 MFMAs per tile and wave, and every tile's 32 x 32 result goes straight to memory.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NKS, int PRO>
+__global__ __launch_bounds__(256, 2) void gemm_split_strip_kernel(SArgs a) {
+    const fdn_conv1x1_desc& d = a.d;
+    constexpr int UNITS = 3 * NKS * 2 * 32;              // 16-byte units of one 32-channel weight tile
+    constexpr int PER = (UNITS + 255) / 256;
+    __shared__ fdn_u32x4 Ws[2][UNITS];
+    __shared__ __attribute__((aligned(16))) float bs[STRIP_MAX_N];
+    const int K = d.K, N = d.N;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, ln = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nch = (K + KC - 1) / KC;
+    const unsigned S = xcd_contiguous(blockIdx.x, (unsigned)a.total_ptiles);
+    const int b = (int)(S / (unsigned)a.tiles_per_img);
+    const unsigned p0 = (S - (unsigned)b * a.tiles_per_img) * TP;
+    const unsigned p = p0 + (unsigned)(wave * 32 + ln), pix = min(p, P - 1);
+    const rsrc_t rx = mk_rsrc(d.x[0] + (long)b * d.xbs[0], (unsigned)K * P4);
+    const fdn_u32x4* wsrc = reinterpret_cast<const fdn_u32x4*>(d.wpk);
+
+    // weight tile t (32 channels) as laid out by fdn_conv1x1_pack: unit u = ((part NKS + ks8) 2 + kh) 32 + n of the tile
+    fdn_u32x4 wv[PER];
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int u = tid + 256 * i;
+            const int n = u & 31, h = (u >> 5) & 1, q = u >> 6, ks8 = q % NKS, part = q / NKS;
+            const long src = ((((long)(t >> 2) * nch + (ks8 >> 1)) * 3 + part) * 2 + (ks8 & 1)) * 256 + h * 128 + (t & 3) * 32 + n;
+            if (UNITS % 256 == 0 || u < UNITS) wv[i] = wsrc[src];
+        }
+    };
+    auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (UNITS % 256 == 0 || tid + 256 * i < UNITS) Ws[buf][tid + 256 * i] = wv[i];
+    };
+    fetch(0);
+
+    // ---- the strip: lane (pixel ln, half kh) holds k = 16 ks + 8 kh + j of its pixel, normalised, as three bf16 parts ----
+    fdn_u32x4 Bf[NKS][3];
+    {
+        float sa = 1.f, sb = 0.f;
+        if (PRO == FDN_PRO_LN) {
+            const float* sp = d.stats + (long)b * 2 * P;
+            sa = sp[P + pix];
+            sb = -sp[pix] * sa;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = bload(rx, pix * 4u + (unsigned)(kh * 8) * P4, (unsigned)(ks * 16 + j) * P4);     // k >= K reads 0
+            if (PRO == FDN_PRO_LN) {                 // (k >= K: any finite value will do, its packed weight is 0)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sa, sb);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[2 * j], x1 = v[2 * j + 1];
+                Bf[ks][0][j] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+                const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+                Bf[ks][1][j] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+                Bf[ks][2][j] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+            }
+        }
+    }
+    stash(0);
+    for (int i = tid; i < STRIP_MAX_N; i += 256) bs[i] = (d.bias && i < N) ? d.bias[i] : 0.f;
+    __syncthreads();
+
+    const rsrc_t ro = mk_rsrc(d.out + (long)b * d.obs, (unsigned)N * P4);
+    const unsigned voff = p < P ? (4u * kh * P + p) * 4u : 0x80000000u;
+    const int ntl = (N + 31) / 32;
+    for (int t = 0; t < ntl; ++t) {
+        if (t + 1 < ntl) fetch(t + 1);
+        const fdn_u32x4* wb = Ws[t & 1] + kh * 32 + ln;
+        f32x16 acc;                               // starts from the bias (LDS copy: a global load here would wait behind the stores)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(&bs[t * 32 + 8 * g + 4 * kh]);
+            acc[4 * g] = bv.x, acc[4 * g + 1] = bv.y, acc[4 * g + 2] = bv.z, acc[4 * g + 3] = bv.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const fdn_u32x4 a1 = wb[((0 * NKS + ks) * 2) * 32], a2 = wb[((1 * NKS + ks) * 2) * 32], a3 = wb[((2 * NKS + ks) * 2) * 32];
+            acc = mf(a3, Bf[ks][0], acc);
+            acc = mf(a2, Bf[ks][1], acc);
+            acc = mf(a1, Bf[ks][2], acc);
+            acc = mf(a2, Bf[ks][0], acc);
+            acc = mf(a1, Bf[ks][1], acc);
+            acc = mf(a1, Bf[ks][0], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nrow = t * 32 + (r & 3) + 8 * (r >> 2);          // + 4 kh per lane
+            bstore(acc[r], ro, voff, (unsigned)nrow * P4);             // rows >= N fall outside the descriptor
+        }
+        if (t + 1 < ntl) stash((t + 1) & 1);
+        __syncthreads();
+    }
+}
+
+template <int NKS, int PRO>
+int launch_strip(const fdn_conv1x1_desc& d, hipStream_t s) {
+    SArgs a;
+    a.d = d;
+    a.tiles_per_img = cdiv(d.P, TP);
+    a.total_ptiles = d.B * a.tiles_per_img;
+    a.ntiles = 1;
+    hipLaunchKernelGGL((gemm_split_strip_kernel<NKS, PRO>), dim3((unsigned)a.total_ptiles), dim3(256), 0, s, a);
+    return fdn_launch_status();
+}
+
 // one thread per 16-byte unit of the packed weights: 8 consecutive k' of one output row, one of the three bf16 parts
 __global__ void pack_split_kernel(const float* __restrict__ w, fdn_u32x4* __restrict__ out, int N, int K, int E, int nch, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,6 +449,13 @@ int fdn_gemm_split(const fdn_conv1x1_desc& d, hipStream_t s) {
     if (!d.wpk || d.K < 96 || d.N < 96 || d.kseg[1] > 0 || d.kseg[2] > 0 || d.act != FDN_ACT_NONE || d.x_bf16 || d.out_bf16) return FDN_ERR_UNSUPPORTED;
     if (d.stats_out && d.N > TN) return FDN_ERR_UNSUPPORTED;
     if ((long)d.B * cdiv(d.P, TP) * cdiv(d.N, TN) > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
+    // short K, wide N, no epilogue: the activation strip stays in registers and the weights stream
+    if (d.K <= 128 && d.N >= 256 && d.N <= STRIP_MAX_N && d.epi == FDN_EPI_NONE && !d.stats_out && (d.pro == FDN_PRO_NONE || d.pro == FDN_PRO_LN)) {
+        const bool ln = d.pro == FDN_PRO_LN;
+        if (d.K > 112) return ln ? launch_strip<8, FDN_PRO_LN>(d, s) : launch_strip<8, FDN_PRO_NONE>(d, s);
+        if (d.K > 96) return ln ? launch_strip<7, FDN_PRO_LN>(d, s) : launch_strip<7, FDN_PRO_NONE>(d, s);
+        return ln ? launch_strip<6, FDN_PRO_LN>(d, s) : launch_strip<6, FDN_PRO_NONE>(d, s);          // K = 96 (FDN_lolv1)
+    }
     switch (d.pro) {
         case FDN_PRO_NONE: return launch_split<FDN_PRO_NONE>(d, s);
         case FDN_PRO_LN: return launch_split<FDN_PRO_LN>(d, s);

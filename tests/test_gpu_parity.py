@@ -281,7 +281,8 @@ def test_conv1x1_variants(A, K, N, H, W, pro):
 
 @pytest.mark.parametrize("K,N,H,W,pro,epi", [(128, 612, 23, 40, "ln", "none"), (128, 345, 184, 320, "ln", "none"), (459, 128, 23, 41, "ln3", "res"),
                                             (345, 128, 184, 320, "none", "res"), (128, 128, 23, 40, "muladd", "muladd"), (96, 96, 5, 7, "none", "bias"),
-                                            (100, 130, 9, 13, "ln", "res"), (345, 128, 8, 17, "ln3", "none"), (128, 128, 184, 320, "muladd", "muladd")])
+                                            (100, 130, 9, 13, "ln", "res"), (345, 128, 8, 17, "ln3", "none"), (128, 128, 184, 320, "muladd", "muladd"),
+                                            (96, 460, 9, 13, "ln", "none"), (100, 300, 9, 13, "none", "bias"), (128, 612, 184, 320, "ln", "bias")])
 def test_conv1x1_split_bf16_kernel(A, K, N, H, W, pro, epi):
     """gemm_split.hip (fp32 GEMM as six bf16 products of exactly split operands) against fp64, every prologue and epilogue,
     ragged K / N / pixel tails, the level-3 shapes of config 2: held to the bounds of the fp32-MFMA kernels (2e-6 relative RMS),
