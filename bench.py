@@ -89,10 +89,6 @@ def describe_call(name, a):
         ob = 2.0 if _iv(a[12]) else 4.0
         f, b = 2.0 * B * H * W * C * 4 * E, B * H * W * (4.0 * C + ob * 4 * E)
         key = f"fdn_fdsa_fused[C={C},E={E},{H}x{W}{',obf16' if ob == 2.0 else ''}]"
-    elif name == "fdn_fdffn_fused":
-        B, C, Hd, H, W = (_iv(v) for v in a[10:15])
-        f, b = 2.0 * B * H * W * C * Hd, 4.0 * B * H * W * (C + Hd)
-        key = f"fdn_fdffn_fused[C={C},Hd={Hd},{H}x{W}]"
     elif name == "fdn_fdsa_core":
         B, E, H, W = (_iv(v) for v in a[4:8])
         b = 4.0 * B * H * W * 8 * E

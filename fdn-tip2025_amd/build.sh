@@ -11,12 +11,13 @@ mkdir -p fdn_hip "$BUILD"
 NOSLP="patchfft ffn_tail"
 OBJS=""
 PIDS=""
+NEWEST_HDR=$(ls -t csrc/*.hpp csrc/*.inc ../include/fdn_hip.h build.sh | head -1)
 for f in csrc/*.hip; do
   n=$(basename "${f%.hip}")
   o=$BUILD/$n.o
   fl=""
   for k in $NOSLP; do [ "$k" = "$n" ] && fl="-fno-slp-vectorize"; done
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ csrc/common.hpp -nt "$o" ] || [ ../include/fdn_hip.h -nt "$o" ] || [ build.sh -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$NEWEST_HDR" -nt "$o" ]; then
     rm -f "$o"                      # a failed compile must not leave a stale object for the link below
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $fl $EXTRA -c "$f" -o "$o" &
     PIDS="$PIDS $!"

@@ -183,3 +183,34 @@ __device__ __forceinline__ void st_store8(const float (&v)[8], __amdgpu_buffer_r
     }
 }
 template <bool BF> constexpr unsigned st_bytes() { return BF ? 2u : 4u; }
+
+// ------------------------------------------------------------------------------------------------
+// fp32 operands for the bf16 matrix pipe (gemm_split.hip has the why).  An fp32 value is cut EXACTLY into three bf16
+// values by truncation: x = x1 + x2 + x3 (8 + 8 + 8 significant bits), and w x = w1 x1 + (w1 x2 + w2 x1) +
+// (w1 x3 + w2 x2 + w3 x1) to below one fp32 rounding.  fdn_split3 cuts the PAIR (a, b) and packs each part as
+// (a | b << 16), the order of two consecutive k of an MFMA operand.
+// ------------------------------------------------------------------------------------------------
+typedef float fdn_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float fdn_trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+__device__ __forceinline__ unsigned fdn_pack_hi16(float a, float b) {
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ void fdn_split3(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = fdn_pack_hi16(a, b);
+    const float ra = a - fdn_trunc_bf16(a), rb = b - fdn_trunc_bf16(b);
+    p2 = fdn_pack_hi16(ra, rb);
+    p3 = fdn_pack_hi16(ra - fdn_trunc_bf16(ra), rb - fdn_trunc_bf16(rb));
+}
+__device__ __forceinline__ fdn_f32x16 fdn_mfma_bf16(fdn_u32x4 a, fdn_u32x4 b, fdn_f32x16 c) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six leading products of one 16-deep k-step, small terms first
+__device__ __forceinline__ fdn_f32x16 fdn_mfma_split6(const fdn_u32x4 (&a)[3], const fdn_u32x4 (&b)[3], fdn_f32x16 c) {
+    c = fdn_mfma_bf16(a[2], b[0], c);
+    c = fdn_mfma_bf16(a[1], b[1], c);
+    c = fdn_mfma_bf16(a[0], b[2], c);
+    c = fdn_mfma_bf16(a[1], b[0], c);
+    c = fdn_mfma_bf16(a[0], b[1], c);
+    return fdn_mfma_bf16(a[0], b[0], c);
+}

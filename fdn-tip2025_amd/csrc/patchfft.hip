@@ -8,121 +8,9 @@
 // Tile = 32 x 64 pixels (4 x 8 patches) of one channel per 256-thread workgroup; thread = (patch,
 // row) computes its own 8 stencil outputs and feeds them straight into the row transform, so the
 // only LDS traffic is the halo tile (one channel at a time, double buffered) and the spectra.
-#include "common.hpp"
+#include "patch_fft.hpp"
 
 namespace {
-
-constexpr int TH = 32, TW = 64;
-constexpr int NP = 32;             // patches per tile
-constexpr int KXS = 9;             // stride between the kx columns of a patch spectrum, in float2 (8 used + 1 pad)
-constexpr int PS = 5 * KXS;        // patch stride: column-phase thread t = 5 * patch + kx sits at 9 t float2 = 18 t dwords, so the
-                                   // 8-byte accesses of 16 / 32 consecutive threads fall into distinct banks (with 8 / 41 the kx = 0
-                                   // and kx = 4 columns of a patch shared their banks: 2-3x the LDS cycles in the column phase)
-constexpr float C8 = 0.70710678118654752440f;
-
-// The three 8-point transforms are written on (re, im) PAIRS (ext-vector float2): a complex add / subtract is one
-// v_pk_add_f32, a multiplication by +-i a swizzle the compiler folds into op_sel / neg modifiers, a real scale one v_pk_mul_f32.
-// On gfx950 a wave64 v_pk_* instruction takes ~4.5 issue cycles against 4 for a scalar one (tools/micro/mfma_valu_coexec.hip), so
-// the packed forms cost a little over half the vector-ALU time of the component-wise ones (fft8: 37 instructions instead of 64).
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 mul_pi(f2 a) { return f2{-a.y, a.x}; }      // * (+i)
-__device__ __forceinline__ f2 mul_ni(f2 a) { return f2{a.y, -a.x}; }      // * (-i)
-__device__ __forceinline__ f2 cconj(f2 a) { return f2{a.x, -a.y}; }
-__device__ __forceinline__ f2 tof2(float2 a) { return f2{a.x, a.y}; }
-__device__ __forceinline__ float2 tofloat2(f2 a) { return make_float2(a.x, a.y); }
-
-// in-place 8-point complex FFT, natural order in and out.  INV: e^{+...}, unscaled.
-template <bool INV>
-__device__ __forceinline__ void fft8(float2 (&vv)[8]) {
-    f2 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = tof2(vv[i]);
-    auto rot = [](f2 d) { return INV ? mul_pi(d) : mul_ni(d); };         // * e^{-+ i pi/2}
-    f2 a[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a[i] = v[i] + v[i + 4];
-        const f2 d = v[i] - v[i + 4];
-        if (i == 0) a[4] = d;
-        else if (i == 1) a[5] = C8 * (d + rot(d));                         // * e^{-+ i pi/4}
-        else if (i == 2) a[6] = rot(d);
-        else a[7] = C8 * (rot(d) - d);                                     // * e^{-+ 3 i pi/4}
-    }
-    f2 c[8];
-#pragma unroll
-    for (int h = 0; h < 8; h += 4) {
-        c[h] = a[h] + a[h + 2];
-        c[h + 2] = a[h] - a[h + 2];
-        c[h + 1] = a[h + 1] + a[h + 3];
-        c[h + 3] = rot(a[h + 1] - a[h + 3]);
-    }
-    constexpr int br[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-#pragma unroll
-    for (int h = 0; h < 8; h += 2) {
-        vv[br[h]] = tofloat2(c[h] + c[h + 1]);
-        vv[br[h + 1]] = tofloat2(c[h] - c[h + 1]);
-    }
-}
-
-// forward real row transform: 8 reals -> bins 0..4, through one 4-point complex FFT of
-// z[n] = x[2n] + i x[2n+1] and the split  X[k] = E[k] + W8^k O[k]
-__device__ __forceinline__ void rfft8_row(const float (&x)[8], float2 (&o)[5]) {
-    const f2 z0 = {x[0], x[1]}, z1 = {x[2], x[3]}, z2 = {x[4], x[5]}, z3 = {x[6], x[7]};
-    const f2 s02 = z0 + z2, d02 = z0 - z2, s13 = z1 + z3, d13 = z1 - z3;
-    const f2 Z0 = s02 + s13, Z2 = s02 - s13;
-    const f2 Z1 = d02 + mul_ni(d13);                  // d02 - i d13
-    const f2 Z3 = d02 + mul_pi(d13);                  // d02 + i d13
-    o[0] = make_float2(Z0.x + Z0.y, 0.f);
-    o[4] = make_float2(Z0.x - Z0.y, 0.f);
-    o[2] = tofloat2(cconj(Z2));
-    // k = 1: E = (Z1 + conj Z3)/2, D = (Z1 - conj Z3)/2, O = -i D, X1 = E + W8 O, W8 = (c, -c);  k = 3: X3 = conj(E - W8 O)
-    const f2 cz3 = cconj(Z3);
-    const f2 e = 0.5f * (Z1 + cz3), d = 0.5f * (Z1 - cz3);
-    const f2 oo = mul_ni(d);
-    const f2 t = C8 * (oo + mul_ni(oo));              // W8 * O = c (oo.x + oo.y, oo.y - oo.x)
-    o[1] = tofloat2(e + t);
-    o[3] = tofloat2(cconj(e - t));
-}
-
-// inverse c2r row transform from bins 0..4 (imag of bins 0 and 4 ignored, like pocketfft/MKL c2r),
-// unscaled: returns 8 * x, through one 4-point complex inverse FFT
-__device__ __forceinline__ void irfft8_row(const float2 (&X)[5], float (&x)[8]) {
-    const f2 Z0 = {X[0].x + X[4].x, X[0].x - X[4].x};
-    const f2 Z2 = 2.f * cconj(tof2(X[2]));
-    // k = 1: E' = X1 + conj X3, D' = X1 - conj X3, O' = D' * (c, c), Z1 = E' + i O';  k = 3: Z3 = conj(E') + i O3', O3' = conj-mirrored
-    const f2 x1 = tof2(X[1]), cx3 = cconj(tof2(X[3]));
-    const f2 e1 = x1 + cx3, d1 = x1 - cx3;
-    const f2 o1 = C8 * (d1 + mul_pi(d1));             // c (d1.x - d1.y, d1.x + d1.y)
-    const f2 Z1 = e1 + mul_pi(o1);                    // (e1.x - o1.y, e1.y + o1.x)
-    const f2 Z3 = cconj(e1 - mul_pi(o1));             // the k = 3 bin of the half-length transform
-    const f2 s02 = Z0 + Z2, d02 = Z0 - Z2, s13 = Z1 + Z3, d13 = Z1 - Z3;
-    const f2 r0 = s02 + s13, r2 = s02 - s13;
-    const f2 r1 = d02 + mul_pi(d13);                  // d02 + i d13
-    const f2 r3 = d02 + mul_ni(d13);                  // d02 - i d13
-    x[0] = r0.x; x[1] = r0.y; x[2] = r1.x; x[3] = r1.y; x[4] = r2.x; x[5] = r2.y; x[6] = r3.x; x[7] = r3.y;
-}
-
-__device__ __forceinline__ float rsq(float v) { return __builtin_amdgcn_rsqf(v); }
-
-// buffer resources: per-lane byte offsets are computed once per workgroup (invalid lanes get an offset past
-// num_records, which loads as 0 and drops stores); the channel plane is a scalar offset, so walking planes
-// costs no vector ALU work (these kernels are VALU-issue bound, not HBM bound)
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0x80000000u;       // images are limited to < 2 GB per tensor so that OOB (+ small immediates) stays out of range
-__device__ __forceinline__ rsrc_t mk_rsrc(const float* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float bload(rsrc_t r, unsigned voff, unsigned soff) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bstore8(const float (&v)[8], rsrc_t r, unsigned voff, unsigned soff) {
-    u32x4 a, b;
-    a.x = __float_as_uint(v[0]); a.y = __float_as_uint(v[1]); a.z = __float_as_uint(v[2]); a.w = __float_as_uint(v[3]);
-    b.x = __float_as_uint(v[4]); b.y = __float_as_uint(v[5]); b.z = __float_as_uint(v[6]); b.w = __float_as_uint(v[7]);
-    __builtin_amdgcn_raw_buffer_store_b128(a, r, voff, soff, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(b, r, voff + 16u, soff, 0);
-}
 
 // ------------------------------------------------------------------------------------------
 // halo tiles: (TH+2) x (TW+2) floats of one plane, row stride HS (odd: thread (patch,row) reads hit
@@ -491,7 +379,7 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int xx = tx0 - 1 + c0 + j;
-                mid[r * LSM + c0 + j] = (yok && xx >= 0 && xx < W) ? gelu_fast(o8[j]) : 0.f;
+                mid[r * LSM + c0 + j] = (yok && xx >= 0 && xx < W) ? gelu_fast(o8[j]) : 0.f;     // (a select around an unconditional GELU measured slower: 2.18 vs 1.83 ms)
             }
         };
         ring_segment(tid);                                        // 256 of the 272 segments
@@ -577,11 +465,13 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 //
 // Workgroup = one 8 x 32 pixel tile (1 x 4 patches) of one image, ALL E channels, 256 threads.
 //   * the normalised input strip of the 10 x 34 halo tile (C channels) is loaded once and lives in registers as the
-//     B operand of v_mfma_f32_32x32x2_f32 (pixels on the lane axis, exactly like conv1x1_smallk_kernel): 11 strips of
-//     32 halo pixels, three (waves 0-2) or two (wave 3) per wave, C/2 VGPRs each;
+//     B operand of v_mfma_f32_32x32x16_bf16 (pixels on the lane axis; three exact bf16 parts per value, so the product is
+//     fp32 arithmetic on the bf16 matrix pipe, which - unlike the fp32 MFMA - runs beside the vector ALU): 11 strips of
+//     32 halo pixels, three (waves 0-2) or two (wave 3) per wave, 12 VGPRs per 16 channels each;
 //   * channels are walked in chunks of 8: the 32 MFMA rows of a chunk are (q,k,v,v_value) x 8 channels (weights
-//     packed per chunk / k-step / lane by fdn_fdsa_pack, LayerNorm affine folded in), each wave runs C/2 MFMAs per
-//     strip and parks the 32 x 32 result in the LDS hidden tile (zero outside the image = the conv's zero padding);
+//     packed per chunk / k-step / part / lane by fdn_fdsa_pack, LayerNorm affine folded in), each wave runs 6 MFMAs per
+//     16 channels and strip (+ 1 for the bias) and parks the 32 x 32 result in the LDS hidden tile (zero outside the image
+//     = the conv's zero padding);
 //   * then thread = (channel of the chunk, patch, row): stencil -> row rfft -> LDS spectra -> column phase
 //     (160 threads) -> inverse rows -> 32-byte stores, the code of fdsa_core_kernel.
 // HBM traffic: C planes in (+33 % halo, mostly L2 hits: each XCD owns a contiguous run of tiles), 4E planes out.
@@ -629,9 +519,12 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     const unsigned hwo = P * OES;
     const rsrc_t rout = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.out) + (long)b * 4 * E * P * OES), 4u * E * hwo);
 
-    // ---- the wave's strips of the normalised halo tile: B operands, resident for the whole workgroup ----------
-    float xs[3][C / 2];
-    float xone[3];                      // B operand of the bias k-step: 1 on k = 0 for pixels inside the image, else 0
+    // ---- the wave's strips of the normalised halo tile: B operands of v_mfma_f32_32x32x16_bf16, resident for the whole
+    // workgroup.  Lane (pixel ln, half kh) holds channels k = 16 ks + 8 kh + j, normalised and cut into three exact bf16
+    // parts (common.hpp: fp32 arithmetic on the bf16 matrix pipe); channels k >= C read 0 and meet zero weights.
+    constexpr int KST = (C + 15) / 16;
+    fdn_u32x4 xb[3][KST][3];
+    fdn_u32x4 xone[3];                  // B operand of the bias step: bf16 1.0 on k = 0, 1, 2 (the bias' three parts) inside the image
     int pixoff[3];
 #pragma unroll
     for (int si = 0; si < 3; ++si) {
@@ -641,7 +534,8 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
         const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
         const bool in_tile = s < FNS && p < FHP;
         const bool ok = in_tile && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        xone[si] = (ok && kh == 0) ? 1.f : 0.f;
+        const bool one = ok && kh == 0;
+        xone[si] = fdn_u32x4{one ? 0x3F803F80u : 0u, one ? 0x00003F80u : 0u, 0u, 0u};
         pixoff[si] = in_tile ? r * FRS + c : FHW;                 // lanes past the tile: the unused pad cell of row 0 of each plane
         const unsigned g = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
         float mu = 0.f, rs = 1.f;
@@ -649,12 +543,21 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
             mu = bload(rst, g, 0);
             rs = bload(rst, g, hw4);
         }
+        float xs[KST][8];
 #pragma unroll
-        for (int j = 0; j < C / 2; ++j) xs[si][j] = bload(rx, g + (unsigned)kh * hw4, (unsigned)(2 * j) * hw4);
-        if (LN) {
+        for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
-            for (int j = 0; j < C / 2; ++j) xs[si][j] = (xs[si][j] - mu) * rs;
-        }
+            for (int j = 0; j < 8; ++j) xs[ks][j] = bload(rx, g + (unsigned)(8 * kh) * hw4, (unsigned)(16 * ks + j) * hw4);
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v0 = xs[ks][2 * j], v1 = xs[ks][2 * j + 1];
+                if (LN) v0 = (v0 - mu) * rs, v1 = (v1 - mu) * rs;
+                unsigned p1, p2, p3;
+                fdn_split3(v0, v1, p1, p2, p3);
+                xb[si][ks][0][j] = p1, xb[si][ks][1][j] = p2, xb[si][ks][2][j] = p3;
+            }
     }
 
     // VALU-phase coordinates: lanes 0-31 / 32-63 of a wave take two different channels of the chunk
@@ -668,10 +571,10 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     // Per-chunk operands.  A operands (packed per chunk / k-step / lane by fdn_fdsa_pack, last k-step = the bias row against
     // `xone`): registers, reloaded for the NEXT chunk right after this chunk's MFMAs so the loads fly during the spectral
     // phases.  Depthwise taps and fft gains: one element per thread, staged through LDS a chunk ahead.
-    constexpr int KS = C / 2 + 1;
-    float aw[KS];
+    constexpr int KS = KST * 3 + 1;
+    fdn_u32x4 aw[KS];
     auto aw_fetch = [&](int ch) {
-        const float* wp = a.wpk + ((long)ch * KS) * 64 + lane;
+        const fdn_u32x4* wp = reinterpret_cast<const fdn_u32x4*>(a.wpk) + ((long)ch * KS) * 64 + lane;
 #pragma unroll
         for (int j = 0; j < KS; ++j) aw[j] = wp[j * 64];
     };
@@ -695,12 +598,16 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
         fgs[tid] = st_f0;
         if (tid < 64) fgs[tid + 256] = st_f1;
     };
-    aw_fetch(0);
+    // (C >= 48: the strips alone take 108 / 144 registers, so the A operands are not held across the spectral phases - they are
+    //  fetched at the top of each chunk's MFMA phase, from L2, and the other workgroup of the CU covers the wait)
+    constexpr bool AW_AHEAD = KS <= 7;
+    if (AW_AHEAD) aw_fetch(0);
     stage_fetch(0);
     stage_store();                      // (visible behind the first barrier of the loop)
     for (int ch = 0; ch < a.nchunks; ++ch) {
         const int e0 = ch * FEG;
         const int e = e0 + el;
+        if (!AW_AHEAD) aw_fetch(ch);
         // ---- to_hidden on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes (0 outside the image: the
         // strip, its statistics and `xone` all read 0 there)
 #pragma unroll
@@ -710,15 +617,18 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int j = 0; j < C / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[j], xs[si][j], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[C / 2], xone[si], acc, 0, 0, 0);      // + bias (fma(b, 1, acc) = acc + b)
+                for (int ks = 0; ks < KST; ++ks) {
+                    const fdn_u32x4 a3[3] = {aw[3 * ks], aw[3 * ks + 1], aw[3 * ks + 2]};
+                    acc = fdn_mfma_split6(a3, xb[si][ks], acc);
+                }
+                acc = fdn_mfma_bf16(aw[KS - 1], xone[si], acc);      // + bias: b1 + b2 + b3 against 1, 1, 1 (0 outside the image)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hid[((r & 3) + 8 * (r >> 2) + 4 * kh) * FPL + pixoff[si]] = acc[r];   // row = kind * 8 + channel
             }
         }
         const bool more = ch + 1 < a.nchunks;                       // uniform
         if (more) {
-            aw_fetch(ch + 1);
+            if (AW_AHEAD) aw_fetch(ch + 1);
             stage_fetch(ch + 1);
         }
         __syncthreads();
@@ -818,30 +728,47 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
     }
 }
 
-// fdn_fdsa_pack: [4E][C] weights (+ LayerNorm gamma / beta of the input) -> per (chunk, k-step, lane) A operands; the last
-// k-step of a chunk carries the bias row (W beta, fp64 sum) on k = 0 and zeros on k = 1
+// fdn_fdsa_pack: [4E][C] weights (+ LayerNorm gamma / beta of the input) -> per (chunk, slot, lane) 16-byte A operands of
+// v_mfma_f32_32x32x16_bf16: slot 3 ks + part = the part-th bf16 part of w[row][16 ks + 8 kh + j] * gamma, j = 0..7; the last
+// slot carries the three parts of the bias row (W beta, fp64 sum) on k = 0, 1, 2 of the lower lane half
 __global__ void fdsa_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 float* __restrict__ wpk, int C, int E, int nchunks) {
+                                 fdn_u32x4* __restrict__ wpk, int C, int E, int nchunks) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int KS = C / 2 + 1;
+    const int KST = (C + 15) / 16, KS = KST * 3 + 1;
     if (idx >= nchunks * KS * 64) return;
     const int lane = idx & 63, j = (idx >> 6) % KS, ch = (idx >> 6) / KS;
     const int m = lane & 31, kh = lane >> 5;
     const int e = ch * FEG + (m & 7);
-    float v = 0.f;
+    auto part_of = [](float x, int part) {
+        for (int p = 0; p < part; ++p) x -= __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+        return __float_as_uint(x) >> 16;
+    };
+    fdn_u32x4 o = {0u, 0u, 0u, 0u};
     if (e < E) {
         const float* wr = w + (long)((m >> 3) * E + e) * C;
-        if (j < C / 2) {
-            const int k = 2 * j + kh;
-            v = wr[k];
-            if (gamma) v *= gamma[k];
+        if (j < KS - 1) {
+            const int ks = j / 3, part = j - 3 * ks;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned hl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = 16 * ks + 8 * kh + 2 * q + u;
+                    float v = k < C ? wr[k] : 0.f;
+                    if (gamma && k < C) v *= gamma[k];
+                    hl[u] = part_of(v, part);
+                }
+                o[q] = hl[0] | (hl[1] << 16);
+            }
         } else if (kh == 0 && beta) {
             double sacc = 0.0;
             for (int k = 0; k < C; ++k) sacc += (double)wr[k] * (double)beta[k];
-            v = (float)sacc;
+            const float bsum = (float)sacc;
+            o[0] = part_of(bsum, 0) | (part_of(bsum, 1) << 16);
+            o[1] = part_of(bsum, 2);
         }
     }
-    wpk[idx] = v;
+    wpk[idx] = o;
 }
 
 }  // namespace
@@ -887,9 +814,9 @@ extern "C" int fdn_fdffn_mid(const void* x_, const float* w0, const float* w2, c
 extern "C" int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, fdn_stream_t stream) {
     FDN_CHECK_ARG(w && wpk && C > 0 && C % 2 == 0 && E > 0 && (!gamma == !beta));
     const int nch = (E + FEG - 1) / FEG;
-    const int total = nch * (C / 2 + 1) * 64;
-    hipLaunchKernelGGL(fdsa_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma, beta, wpk,
-                       C, E, nch);
+    const int total = nch * (((C + 15) / 16) * 3 + 1) * 64;
+    hipLaunchKernelGGL(fdsa_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma, beta,
+                       reinterpret_cast<fdn_u32x4*>(wpk), C, E, nch);
     return fdn_launch_status();
 }
 

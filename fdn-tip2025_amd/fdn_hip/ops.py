@@ -219,7 +219,7 @@ def fdsa_pack(w, gamma, beta):
     E4, C = w.shape[0], w.shape[1]
     E = E4 // 4
     nch = (E + 7) // 8
-    wpk = torch.empty((nch, C // 2 + 1, 64), device=w.device, dtype=torch.float32)
+    wpk = torch.empty((nch, 3 * ((C + 15) // 16) + 1, 64, 4), device=w.device, dtype=torch.float32)      # 16-byte bf16 operand fragments
     check(lib().fdn_fdsa_pack(_flat(w.reshape(E4, C), "w"), _flat(gamma, "gamma"), _flat(beta, "beta"), _flat(wpk, "wpk"),
                               C, E, stream()), "fdn_fdsa_pack")
     return wpk

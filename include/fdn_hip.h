@@ -116,7 +116,8 @@ int fdn_fdsa_core(const float* hidden, const float* dw_w, const float* fft_w, fl
  * to_hidden (1x1 conv C -> 4E on the matrix cores, evaluated on the 1-pixel halo of each 8x32 tile) and everything
  * fdn_fdsa_core does; the 4E-channel hidden tensor never reaches HBM.
  * fdn_fdsa_pack: to_hidden weight w [4E][C] (+ optional LayerNorm gamma, beta [C], folded in: w*diag(gamma), w@beta)
- *   -> wpk [ceil(E/8)][C/2+1][64] (MFMA A operands per chunk of 8 channels, k-step, lane; the last k-step is the bias row).
+ *   -> wpk [ceil(E/8)][3*ceil(C/16)+1][64][4] dwords (bf16 MFMA A operands per chunk of 8 channels, (k-step, part), lane: every
+ *   weight is cut exactly into three bf16 parts, see fdn_conv1x1_pack; the last slot carries the bias row's three parts).
  * fdn_fdsa_fused: x [B][C][H][W] (batch stride xbs), stats [B][2][P] = (mean, rstd) of x over C or NULL (no
  *   LayerNorm; then pack without gamma / beta), dw_w [4E][9], fft_w [E][8][5]
  *   -> out [B][4E][H][W] = (out1|out2|out3|v_value_dw), exactly fdn_fdsa_core's output.

@@ -33,29 +33,41 @@ def _rnd(*shape, seed=0):
 @pytest.mark.parametrize("C,H,W,B,ln", [(32, 32, 64, 2, True), (32, 40, 48, 1, True), (64, 16, 40, 2, True), (24, 24, 72, 2, True),
                                         (48, 8, 8, 3, True), (32, 16, 32, 1, False), (64, 368, 640, 1, True)])
 def test_fdsa_fused_equals_unfused(A, C, H, W, B, ln):
-    """fdn_fdsa_fused (LayerNorm + to_hidden on the matrix cores + core, one launch) against fdn_conv1x1 ->
-    fdn_fdsa_core on the same inputs: same MFMA chain order and the same spectral code, so equal to rounding."""
+    """fdn_fdsa_fused (LayerNorm + to_hidden on the bf16 matrix pipe with exactly split fp32 operands + core, one launch)
+    against fdn_conv1x1 (fp32 MFMA) -> fdn_fdsa_core on the same inputs, both held to the float64 oracle: the fused launch may
+    not be further from float64 than the unfused one beyond the conditioning-aware bound of the block tests."""
+    from common import assert_close_cond
     from fdn_hip import ops
     E = int(C * 1.2)
-    x = dev(_rnd(B, C, H, W, seed=1) * 1.5 + 0.3)
-    w = dev(_rnd(4 * E, C, seed=2) / C ** 0.5)
-    g, b_ = dev(_rnd(C, seed=3) * 0.2 + 1.0), dev(_rnd(C, seed=4) * 0.1)
-    dw, fw = dev(_rnd(4 * E, 1, 3, 3, seed=5) / 3), dev(_rnd(E, 1, 1, 8, 5, seed=6) * 0.2 + 1.0)
+    x = _rnd(B, C, H, W, seed=1) * 1.5 + 0.3
+    w = _rnd(4 * E, C, seed=2) / C ** 0.5
+    g, b_ = _rnd(C, seed=3) * 0.2 + 1.0, _rnd(C, seed=4) * 0.1
+    dw, fw = _rnd(4 * E, 1, 3, 3, seed=5) / 3, _rnd(E, 1, 1, 8, 5, seed=6) * 0.2 + 1.0
+    xd, wd, gd, bd, dwd, fwd = dev(x), dev(w), dev(g), dev(b_), dev(dw), dev(fw)
     if ln:
-        st = ops.chan_stats(x)
-        hidden = ops.conv1x1(x, w, ln=(st, g, b_))
-        wpk = ops.fdsa_pack(w, g, b_)
+        st = ops.chan_stats(xd)
+        hidden = ops.conv1x1(xd, wd, ln=(st, gd, bd))
+        wpk = ops.fdsa_pack(wd, gd, bd)
     else:
         st = None
-        hidden = ops.conv1x1(x, w)
-        wpk = ops.fdsa_pack(w, None, None)
-    ref = ops.fdsa_core(hidden, dw, fw)
-    got = ops.fdsa_fused(x, st, wpk, dw, fw)
+        hidden = ops.conv1x1(xd, wd)
+        wpk = ops.fdsa_pack(wd, None, None)
+    ref = ops.fdsa_core(hidden, dwd, fwd)
+    got = ops.fdsa_fused(xd, st, wpk, dwd, fwd)
     torch.cuda.synchronize()
     assert torch.isfinite(got).all()
-    err = (got - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 2e-6, err
-    assert rel_rms(got.cpu(), ref.cpu()) < 1e-7
+    # float64 truth of the same front half (oracle/fdn_oracle.py fdsa, taps = the inputs of norm1/2/3 and v_value)
+    D = torch.float64
+    xin = O.ln_chan(x.to(D), g.to(D), b_.to(D)) if ln else x.to(D)
+    P = {"a.to_hidden.weight": w.to(D).view(4 * E, C, 1, 1), "a.to_hidden_dw.weight": dw.to(D), "a.fft": fw.to(D),
+         "a.project_out.weight": torch.zeros(1, 3 * E, 1, 1, dtype=D)}
+    for n in ("norm1", "norm2", "norm3"):
+        P[f"a.{n}.body.weight"], P[f"a.{n}.body.bias"] = torch.ones(E, dtype=D), torch.zeros(E, dtype=D)
+    taps = {}
+    O.fdsa(xin, P, "a", taps)
+    truth = torch.cat([taps["o1"], taps["o2"], taps["o3"], taps["vv"]], 1)
+    e_got, e_ref = assert_close_cond(got, ref, truth, f"fdsa_fused C={C}")
+    print(f"fdsa_fused C={C} {H}x{W}: relative RMS error vs float64: fused {e_got:.2e}, unfused {e_ref:.2e}")
 
 
 def test_fdsa_fused_batch_slices_and_edges(A):
@@ -71,7 +83,7 @@ def test_fdsa_fused_batch_slices_and_edges(A):
     wpk = ops.fdsa_pack(w, g, b_)
     got = ops.fdsa_fused(x, st, wpk, dw, fw)
     ref = ops.fdsa_core(ops.conv1x1(x.contiguous(), w, ln=(st, g, b_)), dw, fw)
-    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+    assert rel_rms(got.cpu(), ref.cpu()) < 2e-6          # (different multipliers, fp32 both: equal to rounding, amplified by the phase arithmetic)
 
 
 def test_forward_streams_cold_start(A):

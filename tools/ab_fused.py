@@ -35,6 +35,11 @@ for lvl in (1, 2):
     h = r(B, Hd, H, W)
     w0, w2, fa, fp = r(Hd, 1, 3, 3), r(Hd, 1, 3, 3), r(Hd, 1, 1, 8, 5), r(Hd, 1, 1, 8, 5)
     print(f"L{lvl} fdffn_mid {timeit(lambda: ops.fdffn_mid(h, w0, w2, fa, fp)):.3f} ms", flush=True)
+    if hasattr(ops, "fdffn_fused") and C in getattr(ops, "FDFFN_FUSED_C", ()):
+        wi = r(Hd, C) / C ** .5
+        pk = ops.fdffn_pack(wi, g, b_, fa, fp)
+        print(f"L{lvl} conv1x1 ffn_in {timeit(lambda: ops.conv1x1(x, wi, ln=(st, g, b_))):.3f} ms", flush=True)
+        print(f"L{lvl} fdffn_fused {timeit(lambda: ops.fdffn_fused(x, st, pk, w0, w2)):.3f} ms", flush=True)
     wg = r(2 * Hd, 1, 3, 3)
     print(f"L{lvl} dwconv_gate {timeit(lambda: ops.dwconv_gate(h, wg)):.3f} ms", flush=True)
     hid = r(B, 4 * E, H, W)
