@@ -379,7 +379,11 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int xx = tx0 - 1 + c0 + j;
+#ifdef FDN_KO_GELU
+                mid[r * LSM + c0 + j] = (yok && xx >= 0 && xx < W) ? o8[j] : 0.f;
+#else
                 mid[r * LSM + c0 + j] = (yok && xx >= 0 && xx < W) ? gelu_fast(o8[j]) : 0.f;     // (a select around an unconditional GELU measured slower: 2.18 vs 1.83 ms)
+#endif
             }
         };
         ring_segment(tid);                                        // 256 of the 272 segments
@@ -412,6 +416,9 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
         // ---- B: tin is free: park the prefetched halo; second conv; column transforms --------------
         if (more) stash();
         float sp[8];
+#if defined(FDN_KO_DW2)
+        for (int j = 0; j < 8; ++j) sp[j] = mid[(py * 8 + rr + 1) * LSM + px * 8 + j + 1];
+#else
         {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sp[j] = 0.f;
@@ -426,8 +433,13 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
                     for (int dx = 0; dx < 3; ++dx) sp[j] = fmaf(k2[dy * 3 + dx], v[j + dx], sp[j]);
             }
         }
+#endif
         // columns: forward, z * ffta * e^{-i fftp}, inverse  (FDN_arch.py:460-469)
+#ifdef FDN_KO_COL
+        if (tid < 0) {
+#else
         if (tid < NP * 5) {
+#endif
             const int pj = tid / 5, kx = tid - pj * 5;
             float2 z[8];
 #pragma unroll
@@ -452,6 +464,9 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
             irfft8_row(xk, r);
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] += sp[j];                                                              // :470
+#ifdef FDN_KO_STORE
+            if (r[0] == 123.456f)
+#endif
             st_store8<OBF>(r, rout, ooff, (unsigned)c * hwo);
         }
         __syncthreads();                                          // S, mid, filt are rewritten by the next channel
@@ -612,7 +627,11 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
         // strip, its statistics and `xone` all read 0 there)
 #pragma unroll
         for (int si = 0; si < 3; ++si) {
+#ifdef FDN_KOF_MFMA
+            if (ch == 0 && wave + 4 * si < FNS) {
+#else
             if (wave + 4 * si < FNS) {                              // wave-uniform
+#endif
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -633,18 +652,19 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
         }
         __syncthreads();
 
-        // ---- rows: depthwise 3x3 (to_hidden_dw, FDN_arch.py:578) + forward row transforms; v_value goes straight out
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float* hp = hb + t * 8 * FPL;
+        // ---- rows: depthwise 3x3 (to_hidden_dw, FDN_arch.py:578) + forward row transforms of q, k, v (v_value: see the column phase)
+        auto dw_row8 = [&](const float* hp, const float* wk9, float (&o8)[8]) __attribute__((always_inline)) {
             float wkt[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) wkt[i] = wks[(t * 8 + el) * 9 + i];
-            float o8[8];
+            for (int i = 0; i < 9; ++i) wkt[i] = wk9[i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+#ifdef FDN_KOF_STENCIL
+            for (int dy = 1; dy < 2; ++dy) {
+#else
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
+#endif
                 float v[10];
 #pragma unroll
                 for (int j = 0; j < 10; ++j) v[j] = hp[dy * FRS + j];
@@ -653,19 +673,24 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) o8[j] = fmaf(wkt[dy * 3 + dx], v[j + dx], o8[j]);
             }
-            if (t < 3) {
-                float2 sp[5];
-                rfft8_row(o8, sp);
+        };
 #pragma unroll
-                for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * KXS + row] = sp[kx];
-            } else {
-                st_store8<OBF>(o8, rout, e < E ? opix + (unsigned)(3 * E + e) * hwo : OOB, 0);
-            }
+        for (int t = 0; t < 3; ++t) {
+            float o8[8];
+            dw_row8(hb + t * 8 * FPL, wks + (t * 8 + el) * 9, o8);
+            float2 sp[5];
+            rfft8_row(o8, sp);
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * KXS + row] = sp[kx];
         }
         __syncthreads();
 
         // ---- columns: thread = (slot, kx): forward, recombine, inverse (as fdsa_core_kernel) ------------------------
+#ifdef FDN_KOF_COL
+        if (tid < 0) {
+#else
         if (tid < NP * 5) {
+#endif
             const int pj = tid / 5, kx = tid - pj * 5;
             float2 q[8], k[8], v[8];
 #pragma unroll
@@ -681,8 +706,13 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
             fft8<false>(k);
             fft8<false>(v);
             float2 o1[8], o2[8], o3[8];
+#ifdef FDN_KOF_RECOMB
+            for (int ky = 0; ky < 8; ++ky) { o1[ky] = q[ky]; o2[ky] = k[ky]; o3[ky] = make_float2(v[ky].x * fg[ky], v[ky].y); }
+            for (int ky = 8; ky < 8; ++ky) {
+#else
 #pragma unroll
             for (int ky = 0; ky < 8; ++ky) {
+#endif
                 const float f = fg[ky];
                 const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));            // :591-593
                 float2 qk = cmul(q[ky], k[ky]);                                               // :595
@@ -709,6 +739,19 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
                 S[(1 * NP + pj) * PS + kx * KXS + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
                 S[(2 * NP + pj) * PS + kx * KXS + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
             }
+        } else if (wave == 3) {
+            // the 160 column jobs fill waves 0-2: wave 3, idle otherwise, runs the whole chunk's v_value path meanwhile (depthwise
+            // conv of the fourth kind straight to global: no transform) - four (channel, patch, row) jobs per lane
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const int elv = 2 * i + kh, ev = e0 + elv;
+                float o8[8];
+                dw_row8(hid + (24 + elv) * FPL + row * FRS + px * 8, wks + (24 + elv) * 9, o8);
+#ifdef FDN_KOF_STORE
+                if (o8[0] == 123.456f)
+#endif
+                st_store8<OBF>(o8, rout, ev < E ? opix + (unsigned)(3 * E + ev) * hwo : OOB, 0);
+            }
         }
         __syncthreads();
 
@@ -720,6 +763,9 @@ __global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
             for (int kx = 0; kx < 5; ++kx) xk[kx] = S[(t * NP + slot) * PS + kx * KXS + row];
             float r8[8];
             irfft8_row(xk, r8);
+#ifdef FDN_KOF_STORE
+            if (r8[0] == 123.456f)
+#endif
             st_store8<OBF>(r8, rout, e < E ? opix + (unsigned)(t * E + e) * hwo : OOB, 0);
         }
         if (more) stage_store();        // taps (last read before the second barrier) and gains (before the third) of the next chunk
