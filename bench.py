@@ -219,15 +219,51 @@ def kernel_roofline(key, rec, traffic):
     return out
 
 
-def pmc_traffic_by_group():
-    """HBM bytes per launch of each kernel group from the committed rocprofv3 PMC passes (the newest
-    profiles/*traffic_groups.json, written by tools/profile_merge.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs over one
-    launch of each group, corrected per load form as that file documents).  {} when no profile is committed."""
+def pmc_traffic_by_group(shape, dtype):
+    """HBM bytes per launch of each kernel group from the committed rocprofv3 PMC passes: the newest
+    profiles/*traffic_groups.json (written by tools/profile_merge.py: the memory-side request counters by size, FETCH_SIZE and
+    WRITE_SIZE beside them, each in its own --pmc run over one logged forward) whose [batch, height, width] and storage dtype
+    are the ones being benchmarked - bytes per launch depend on all of them.  {} when no matching profile is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_groups.json")))
-    if not files:
-        return {}
-    return {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(files[-1]))["groups"].items()}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_groups.json")), reverse=True):
+        d = json.load(open(f))
+        if list(d.get("shape", [])) == list(shape) and d.get("dtype", "f32") == dtype:
+            return {k: v["hbm_bytes_per_launch"] for k, v in d["groups"].items()}
+    return {}
+
+
+def rank_cpus(local_rank, world):
+    """Host cores for this rank (one process per GPU; ~2,400 launches per step are issued from Python, so eight ranks must not pile
+    onto the same cores or sit across the socket from their GPU).  GPU r's NUMA-local cores from sysfs (amdgpu PCI functions in
+    bus order, `local_cpulist`), cut evenly between the ranks that share them; an even cut of the allowed cores when sysfs has
+    nothing to say.  Read-only, before any GPU call, no exec."""
+    import glob
+    allowed = sorted(os.sched_getaffinity(0))
+
+    def cpulist(txt):
+        out = set()
+        for part in txt.strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                out.update(range(int(lo), int(hi or lo) + 1))
+        return out
+
+    local = []
+    for dev_dir in sorted(glob.glob("/sys/bus/pci/drivers/amdgpu/0000:*")):
+        try:
+            local.append(frozenset(cpulist(open(os.path.join(dev_dir, "local_cpulist")).read()) & set(allowed)))
+        except OSError:
+            pass
+    if len(local) >= world and local[local_rank]:
+        mine = local[local_rank]
+        sharers = [r for r in range(world) if local[r] == mine]
+        cores = sorted(mine)
+        k, n = sharers.index(local_rank), len(sharers)
+        cut = cores[k * len(cores) // n:(k + 1) * len(cores) // n]
+        if cut:
+            return cut, "numa-local (sysfs local_cpulist)"
+    cut = allowed[local_rank * len(allowed) // world:(local_rank + 1) * len(allowed) // world]
+    return (cut or allowed), "even cut of the allowed cores"
 
 
 def usable_cores():
@@ -290,10 +326,15 @@ def launch_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
     rc = 0
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
-            if rc:
-                break
+        live = list(procs)
+        while live and not rc:                  # poll ALL ranks: whichever fails first ends the job (a rank blocked in a collective
+            for p in list(live):                # behind a dead peer would otherwise hold us until the RCCL watchdog fires)
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    rc = max(rc, abs(code))
+            if live and not rc:
+                time.sleep(0.05)
     finally:
         for p in procs:                        # a failed rank must not leave the others waiting in a collective
             if p.poll() is None:
@@ -319,6 +360,10 @@ def main():
     ap.add_argument("--no-scatter-gather", dest="sg", action="store_false")
     ap.add_argument("--variant", choices=("lolblur", "lolv1"), default="lolblur",
                     help="lolblur = FDN (BASELINE.json's metric); lolv1 = FDN_lolv1, dim 24 (SURVEY.md 8(f) rank 1)")
+    ap.add_argument("--no-affinity", action="store_true", help="do not pin the ranks of a multi-GPU run to NUMA-local cores")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the per-rank step from ONE captured HIP graph (all sub-batch streams inside it) instead of ~2,400 "
+                         "eager launches: takes the Python launch work off the host (eight ranks share one host's cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -333,6 +378,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {a.gpus}: the two must agree")
+
+    if a.dry_run and os.environ.get("FDN_BENCH_DRY_FAIL_RANK") == str(rank):
+        sys.exit(3)                                        # rehearsal of a crashed rank (tests/test_multirank_cpu.py)
+    affinity = None
+    if world > 1 and not a.no_affinity:
+        cpus, how = rank_cpus(local_rank, world)
+        os.sched_setaffinity(0, cpus)                      # before the first GPU call of this process
+        affinity = {"cores": len(cpus), "first": cpus[0], "last": cpus[-1], "how": how}
 
     from fdn_hip import sharding
     dist = None
@@ -368,6 +421,9 @@ def main():
         x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
         mk = lambda r: make_input(a.batch, a.height, a.width, dev, seed=1000 + r)
         forward = lambda t: forward_streams(net, lp, t, a.streams)     # LPNet -> FDN, sub-batches on separate HIP streams
+        if a.graph:
+            from fdn_hip.pipeline import GraphedStep
+            forward = GraphedStep(net, lp, a.streams)
         sync = torch.cuda.synchronize
     B, _, H, W = x.shape
     root_in = root_out = None
@@ -385,6 +441,8 @@ def main():
             dist.barrier()
         sync()
 
+    host_s = [0.0]
+
     def timed(with_sg, steps):
         barrier()
         t0 = time.perf_counter()
@@ -395,6 +453,7 @@ def main():
             step(with_sg)
         if not a.dry_run:
             e1.record()
+        host_s[0] = time.perf_counter() - t0               # host time to ISSUE the K steps (the GPU is still running)
         barrier()
         dt = time.perf_counter() - t0
         if not a.dry_run:
@@ -404,6 +463,7 @@ def main():
     for _ in range(a.warmup):
         step(sg)
     dt = timed(sg, a.steps)                                            # THE measurement: exactly K steps
+    host_issue_ms = host_s[0] / a.steps * 1e3
     dt_nosg = None
     if sg:                                                             # beside it: the same K steps without the collectives
         dt_nosg = timed(False, a.steps)
@@ -421,7 +481,7 @@ def main():
             cur = kt.summary()
             agg = cur if agg is None else {k: (v if v[2] <= agg.get(k, v)[2] else agg[k]) for k, v in cur.items()}
         total_ms = sum(v[2] for v in agg.values())
-        traffic = pmc_traffic_by_group()
+        traffic = pmc_traffic_by_group([B, a.height, a.width], a.dtype)
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][2])
         top = []
         for key, rec in ranked[:3]:
@@ -463,8 +523,10 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                        "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1},
-            "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * 4.0 * P * (ips / world) / (PEAK_HBM_GBS * 1e9),
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph),
+                       "host_issue_ms_per_step": host_issue_ms, "cpu_affinity_rank0": affinity},
+            # B_alg = 7,256 elements per padded pixel x sizeof(elem) - 4 bytes in fp32, 2 in the bf16-storage configuration
+            "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * (ips / world) / (PEAK_HBM_GBS * 1e9),
                            "mfma_f32_frac": F_ALG_PER_PX * P * (ips / world) / (PEAK_F32_MFMA_TF * 1e12)},
             "roofline": roof, "top_kernels": top, "cpu_baseline": cpu,
         }

@@ -123,7 +123,7 @@ class FDFFN(nn.Module):
         self._c = _Cache()
 
     def fused(self, x, ln=None, res=None):
-        st = ops.block_storage(x.shape[1], x.shape[2] * x.shape[3])      # hidden tensors: fp32, or bf16 storage (levels 1-2 in bf16 mode)
+        st = ops.block_storage(x.shape[1], x.shape[2] * x.shape[3], hidden=self.project_in.weight.shape[0])      # hidden tensors: fp32, or bf16 storage (levels 1-2 in bf16 mode)
         h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln, cache=(self._c, "pi"), out_dtype=st)
         y = ops.fdffn_mid(h, _w(self.space[0].weight), _w(self.space[2].weight), _w(self.ffta), _w(self.fftp))
         return ops.ffn_tail(y, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None,

@@ -408,10 +408,14 @@ extern "C" int fdn_resample(const float* x, float* out, long planes, int H, int 
         default: return FDN_ERR_ARG;
     }
     FDN_CHECK_ARG(OH <= 65535);
-    for (long p0 = 0; p0 < oplanes; p0 += 65535) {                  // grid.z limit; the FDN path has <= 8 * 128 planes per call
-        const long np = oplanes - p0 < 65535 ? oplanes - p0 : 65535;
-        const long in_pl = mode == FDN_RS_PIXEL_UNSHUFFLE ? p0 / (r * r) : p0;
-        FDN_CHECK_ARG(mode != FDN_RS_PIXEL_UNSHUFFLE || p0 % (r * r) == 0);
+    // grid.z limit (the FDN path has <= 8 * 128 planes per call): chunks of whole input planes, i.e. a multiple of r * r output
+    // planes for PixelUnshuffle - everything is validated before the first launch, a failed call writes nothing
+    const long rr = mode == FDN_RS_PIXEL_UNSHUFFLE ? (long)r * r : 1;
+    FDN_CHECK_ARG(rr <= 65535);
+    const long chunk = 65535 / rr * rr;
+    for (long p0 = 0; p0 < oplanes; p0 += chunk) {
+        const long np = oplanes - p0 < chunk ? oplanes - p0 : chunk;
+        const long in_pl = p0 / rr;
         const bool quad = OW % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
                           (mode != FDN_RS_BILINEAR_HALF || W % 8 == 0);
         const dim3 qgrid((unsigned)cdiv((long)OH * (OW / 4), 256), (unsigned)np);

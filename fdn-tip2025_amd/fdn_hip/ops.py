@@ -36,11 +36,16 @@ def _flat(t, what, bf16_ok=False):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def block_storage(C, P):
+def block_storage(C, P, hidden=None):
     """Storage dtype of the block-internal activations of an FDSA / FDFFN block of input width C and P pixels:
-    bf16 in bf16-storage mode for the blocks whose kernels carry the bf16 load / store forms (levels 1-2: C <= 64,
-    pixel pairs), fp32 otherwise (level 3 is bound by the matrix cores, not by bytes)."""
-    return BF16 if storage_dtype() == "bf16" and C <= 64 and P % 4 == 0 else torch.float32
+    bf16 in bf16-storage mode for the blocks whose kernels carry the bf16 load / store forms, fp32 otherwise.  The predicate
+    mirrors the library's: levels 1-2 (C <= 64), pixel pairs (P % 4 == 0), and for the FDFFN hidden tensor (width `hidden`)
+    the project_in form that writes bf16 (hidden >= 64 and >= 2 C; a non-stock width such as dim 16 -> 43 stays fp32)."""
+    if storage_dtype() != "bf16" or C > 64 or P % 4:
+        return torch.float32
+    if hidden is not None and (hidden < 64 or hidden < 2 * C):
+        return torch.float32
+    return BF16
 
 
 class WeightCache:
@@ -57,6 +62,9 @@ class WeightCache:
         hit = self._store.get(name)
         cuda = any(p is not None and p.is_cuda for p in srcs)
         cur = torch.cuda.current_stream() if cuda else None
+        # an entry holds references to its source tensors (parameters, or detached aliases of their storage): while it lives
+        # that storage cannot be freed and handed to a NEW parameter at the same address with the same version, so
+        # (pointer, version, device) identifies the source
         if hit is None or hit[0] != key:
             with torch.no_grad():
                 val = build()
@@ -64,7 +72,12 @@ class WeightCache:
             if cuda:
                 ev = torch.cuda.Event()
                 ev.record(cur)
-            hit = (key, val, ev, {cur.cuda_stream} if cuda else set())
+                if hit is not None:                 # other streams may still be reading the operands being replaced
+                    for t in (hit[1] if isinstance(hit[1], (tuple, list)) else (hit[1],)):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            for sid in hit[3]:
+                                t.record_stream(torch.cuda.ExternalStream(sid, device=t.device))
+            hit = (key, val, ev, {cur.cuda_stream} if cuda else set(), tuple(srcs))
             self._store[name] = hit
         elif cuda and cur.cuda_stream not in hit[3]:
             if not torch.cuda.is_current_stream_capturing():       # (a capture is preceded by a synchronising warm-up)

@@ -6,7 +6,11 @@ level-2/3 GEMMs of one sub-batch overlap the HBM-bound stencil / FFT kernels of 
 (+5 % images/s at B = 8 on MI355X, bit-identical outputs).  Multi-GPU sharding (one process per GPU)
 is the same cut one level up, see bench.py.
 """
+import collections
+
 import torch
+
+from . import storage_dtype
 
 _streams = {}
 
@@ -49,15 +53,23 @@ class GraphedForward:
     Usage:  g = GraphedForward(net, lpnet); out = g(x)   # out is overwritten by the next call
     """
 
+    MAX_GRAPHS = 4          # captured graphs kept per instance (least recently used goes first: each pins a private memory pool)
+
     def __init__(self, net, lpnet, warmup=2):
         self.net, self.lpnet, self.warmup = net, lpnet, warmup
-        self._graphs = {}
-        self._params = [p for m in (net, lpnet) for p in list(m.parameters()) + list(m.buffers())]
+        self._graphs = collections.OrderedDict()
+        self._seen = collections.OrderedDict()      # shapes met once, not captured yet (a capture costs two forwards + a pool)
 
     def _weights_signature(self):
         """A captured graph holds raw pointers to the weights and to the derived operands built from them (LayerNorm folds,
-        packed MFMA operands): any in-place update or re-load of a parameter invalidates it."""
-        return (sum(p._version for p in self._params), sum(p.data_ptr() & 0xFFFFFFFF for p in self._params))
+        packed MFMA operands), and was recorded in ONE storage mode: any in-place update, re-load or replacement of a parameter
+        or buffer (the live module tree is re-read on every call) and any change of fdn_hip.storage_dtype() invalidates it."""
+        ps = [p for m in (self.net, self.lpnet) for p in list(m.parameters()) + list(m.buffers())]
+        return (storage_dtype(), len(ps), sum(p._version for p in ps), sum(p.data_ptr() & 0xFFFFFFFF for p in ps))
+
+    def _eager(self, x):
+        with torch.no_grad():
+            return self.net(x, ratio_i=self.lpnet(x), device=x.device)[0]
 
     def _capture(self, x):
         static_x = x.clone()
@@ -75,26 +87,60 @@ class GraphedForward:
     def __call__(self, x):
         key = (tuple(x.shape), x.device.index)
         hit = self._graphs.get(key)
-        if hit is None or hit[3] != self._weights_signature():       # new shape, or the weights changed: capture again
-            self._graphs[key] = hit = self._capture(x)
+        if hit is not None and hit[3] != self._weights_signature():  # the weights or the storage mode changed: capture again
+            del self._graphs[key]
+            hit = None
+        if hit is None:
+            if key not in self._seen:                                # a shape met for the first time (trailing partial batch, odd frame
+                self._seen[key] = True                               # size): run it eagerly; it is captured when it comes back
+                while len(self._seen) > 64:
+                    self._seen.popitem(last=False)
+                return self._eager(x)
+            hit = self._capture(x)
+            self._graphs[key] = hit
+            while len(self._graphs) > self.MAX_GRAPHS:
+                self._graphs.popitem(last=False)
+        self._graphs.move_to_end(key)
         g, static_x, static_out, _ = hit
         static_x.copy_(x)
         g.replay()
         return static_out
 
 
+class GraphedStep:
+    """forward_streams (every sub-batch stream) captured into ONE HIP graph for a fixed input shape and replayed: the ~2,400
+    launches of a B = 8 720p step become one hipGraphLaunch, which takes the Python launch work off the host - what matters
+    when eight ranks share one host (bench.py --graph).  The result tensor is overwritten by the next call."""
+
+    def __init__(self, net, lpnet, n_streams=3):
+        self.net, self.lpnet, self.n = net, lpnet, n_streams
+        self._g = None
+
+    def __call__(self, x):
+        if self._g is None or self._x.shape != x.shape:
+            self._x = x.clone()
+            for _ in range(2):                       # FFT tables, weight caches, stream pool: built outside the capture
+                forward_streams(self.net, self.lpnet, self._x, self.n)
+            torch.cuda.synchronize(x.device)
+            self._g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g):
+                self._out = forward_streams(self.net, self.lpnet, self._x, self.n)
+        self._x.copy_(x)
+        self._g.replay()
+        return self._out
+
+
 GRAPH_BELOW_PIXELS = 1 << 20          # B*H*W under which a forward is launch-bound (256 x 256: 23 ms eager vs ~6 ms of kernels)
-_graphed = {}
 
 
 def run(net, lpnet, x, n_streams=3):
-    """The default way to run LPNet -> FDN on one GPU: hipGraph replay for small inputs (launch-bound), sub-batches on
-    `n_streams` HIP streams for large ones.  Returns result [B,3,H,W] (valid until the next call for the graph path)."""
+    """The default way to run LPNet -> FDN on one GPU: hipGraph replay for small inputs (launch-bound) whose shape recurs,
+    sub-batches on `n_streams` HIP streams for large ones.  Returns result [B,3,H,W] (valid until the next call for the graph path).
+    The GraphedForward lives on the model object (it dies with it)."""
     B, _, H, W = x.shape
     if B * H * W < GRAPH_BELOW_PIXELS:
-        key = (id(net), id(lpnet))
-        g = _graphed.get(key)
-        if g is None or g.net is not net:
-            g = _graphed[key] = GraphedForward(net, lpnet)
+        g = net.__dict__.get("_fdn_graphed")
+        if g is None or g.lpnet is not lpnet:
+            g = net.__dict__["_fdn_graphed"] = GraphedForward(net, lpnet)
         return g(x)
     return forward_streams(net, lpnet, x, n_streams)

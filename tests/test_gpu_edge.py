@@ -225,23 +225,59 @@ def test_bench_rccl_path_on_one_gpu(A):
 
 
 def test_graphed_forward_bit_identical(A):
-    """pipeline.GraphedForward (hipGraph capture + replay of the whole LPNet -> FDN forward) returns exactly the eager result,
-    also on the second replay with new input contents, and re-captures after a weight update."""
+    """pipeline.GraphedForward (hipGraph capture + replay of the whole LPNet -> FDN forward) returns exactly the eager result:
+    a shape met once runs eagerly, the second call captures, later calls replay with new input contents; a weight update, a
+    REPLACED parameter object and a change of the storage mode each force a new capture; at most MAX_GRAPHS graphs live."""
+    import fdn_hip
     from basicsr.models.archs.LPNet_arch import I_predict_net
     from fdn_hip.pipeline import GraphedForward
     net = load(A.FDN(), fdn_weights(tame=0.03))
     lp = load(I_predict_net(), lpnet_weights())
     g = GraphedForward(net, lp)
-    for seed in (1, 2):
-        x = dev(torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(seed)))
+
+    def check(seed, shape=(1, 3, 64, 96)):
+        x = dev(torch.rand(*shape, generator=torch.Generator().manual_seed(seed)))
         with torch.no_grad():
             eager = net(x, ratio_i=lp(x))[0]
         assert torch.equal(g(x), eager), seed
+
+    check(1)
+    assert len(g._graphs) == 0                                  # first sight of the shape: eager, nothing pinned
+    check(2)
+    assert len(g._graphs) == 1                                  # the shape came back: captured
+    check(3)                                                    # replay with new contents
     with torch.no_grad():
-        net.net_p.output.weight.mul_(0.5)                      # a weight update: the replay must not use stale operands
-        x = dev(torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(3)))
-        eager = net(x, ratio_i=lp(x))[0]
-    assert torch.equal(g(x), eager)
+        net.net_p.output.weight.mul_(0.5)                       # an in-place weight update: the replay must not use stale operands
+    check(4)
+    net.net_p.output.weight = torch.nn.Parameter(net.net_p.output.weight.detach().clone() * 2.0)   # a replaced Parameter object
+    check(5)
+    try:
+        fdn_hip.set_storage_dtype("bf16")                       # a graph recorded in fp32 storage must not be replayed in bf16 mode
+        check(6)
+    finally:
+        fdn_hip.set_storage_dtype("f32")
+    check(7)
+    for i, hw in enumerate(((64, 64), (32, 64), (64, 32), (32, 32), (32, 96))):      # more shapes than MAX_GRAPHS, each seen twice
+        check(10 + i, (1, 3) + hw)
+        check(20 + i, (1, 3) + hw)
+    assert len(g._graphs) <= GraphedForward.MAX_GRAPHS
+
+
+def test_graphed_step_equals_forward_streams(A):
+    """pipeline.GraphedStep (bench.py --graph: the three sub-batch streams captured into one HIP graph) returns exactly what
+    forward_streams returns, also on a replay with new contents."""
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from fdn_hip.pipeline import GraphedStep, forward_streams
+    net = load(A.FDN(), fdn_weights(tame=0.03))
+    lp = load(I_predict_net(), lpnet_weights())
+    gs = GraphedStep(net, lp, 3)
+    for seed in (1, 2):
+        x = dev(torch.rand(5, 3, 64, 96, generator=torch.Generator().manual_seed(seed)))
+        ref = forward_streams(net, lp, x, 3)
+        torch.cuda.synchronize()
+        got = gs(x)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), seed
 
 
 def test_graphed_forward_planned_fft_shape(A):
@@ -256,5 +292,6 @@ def test_graphed_forward_planned_fft_shape(A):
     x = dev(torch.rand(1, 3, 736, 320, generator=torch.Generator().manual_seed(5)))
     with torch.no_grad():
         eager = net(x, ratio_i=lp(x))[0]
-    assert torch.equal(g(x), eager)
-    assert torch.equal(g(x), eager)
+    assert torch.equal(g(x), eager)          # first sight: eager
+    assert torch.equal(g(x), eager)          # capture
+    assert torch.equal(g(x), eager)          # replay

@@ -88,3 +88,39 @@ def test_bench_rejects_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_bench_launcher_world_8_with_affinity():
+    """The configs[3] launch shape on the CPU: 8 ranks, each pinned to its own cut of the host cores before any GPU call, the
+    scatter / gather of a global batch of 8 x B through the timed loop (gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run",
+                        "--batch", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["rccl_ranks"] == 8 and line["config"]["global_batch"] == 16
+    aff = line["config"]["cpu_affinity_rank0"]
+    assert aff is not None and aff["cores"] >= 1 and aff["cores"] <= max(1, (os.cpu_count() or 8) // 8 + 1)
+    assert line["config"]["host_issue_ms_per_step"] >= 0.0
+
+
+def test_rank_cpus_partition_the_allowed_cores():
+    sys.path.insert(0, ROOT)
+    import bench
+    allowed = sorted(os.sched_getaffinity(0))
+    cuts = [bench.rank_cpus(r, 4)[0] for r in range(4)]
+    assert all(cuts) and all(set(c) <= set(allowed) for c in cuts)
+    if len(allowed) >= 4:                                       # disjoint when there are enough cores
+        assert len(set().union(*map(set, cuts))) == sum(len(c) for c in cuts)
+
+
+def test_bench_launcher_ends_promptly_when_a_rank_dies():
+    """a rank other than the first that crashes must end the job at once (the survivors would otherwise sit in a
+    collective until the watchdog fires)."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["FDN_BENCH_DRY_FAIL_RANK"] = "2"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and time.time() - t0 < 120

@@ -71,7 +71,8 @@ for i, c in enumerate(calls):
     g["wait_inst"] += s.get("SQ_WAIT_INST_ANY", 0.0)
     g["wave_cycles"] += s.get("SQ_WAVE_CYCLES", 0.0)
 
-NSIMD, out = 1024.0, {"note": __doc__, "shape": json.load(open(f"{src}/calls_trace.json"))["shape"], "groups": {}}
+_meta = json.load(open(f"{src}/calls_trace.json"))
+NSIMD, out = 1024.0, {"note": __doc__, "shape": _meta["shape"], "dtype": _meta.get("dtype", "f32"), "groups": {}}
 tot = {"ms": 0.0, "rd": 0.0, "wr": 0.0, "alg": 0.0, "valu_ms": 0.0, "mfma_ms": 0.0}
 lines = []
 for key, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
@@ -103,7 +104,7 @@ out["total"] = {"kernel_ms": tot["ms"], "read_GB": tot["rd"] / 1e9, "write_GB": 
 json.dump(out, open(dst + "_traffic_groups.json", "w"), indent=1)
 with open(dst + "_summary.txt", "w") as f:
     f.write(f"single-stream forward, sum of library kernels {tot['ms']:.1f} ms; HBM read {tot['rd']/1e9:.1f} GB + write {tot['wr']/1e9:.1f} GB "
-            f"(algorithmic {tot['alg']/1e9:.1f} GB); SIMD time if nothing stalled: vector ALU {tot['valu_ms']:.1f} ms + fp32 MFMA {tot['mfma_ms']:.1f} ms\n")
+            f"(algorithmic {tot['alg']/1e9:.1f} GB); SIMD time if nothing stalled: vector ALU {tot['valu_ms']:.1f} ms + MFMA (fp32 and bf16 pipes) {tot['mfma_ms']:.1f} ms\n")
     f.write("\n".join(lines) + "\n")
 st = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)
 if st:
