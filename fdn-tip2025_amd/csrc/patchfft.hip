@@ -159,24 +159,21 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     __syncthreads();
 
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (t < 3) fetch((t + 1) * E + e);
+    for (int t = 0; t < 3; ++t) {
+        fetch((t + 1) * E + e);
         float wk[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) wk[i] = dww[(t * E + e) * 9 + i];
         float o8[8];
         stencil_row8(halo[t & 1], py * 8 + rr, px * 8, wk, o8);          // to_hidden_dw, FDN_arch.py:578
-        if (t < 3) {
-            float2 sp[5];
-            rfft8_row(o8, sp);
+        float2 sp[5];
+        rfft8_row(o8, sp);
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) S[(t * NP + patch) * PS + kx * KXS + rr] = sp[kx];
-            stash(halo[(t + 1) & 1]);
-        } else {                                                            // v_value goes straight out
-            bstore8(o8, rout, ooff, (unsigned)(3 * E + e) * hw4);
-        }
+        for (int kx = 0; kx < 5; ++kx) S[(t * NP + patch) * PS + kx * KXS + rr] = sp[kx];
+        stash(halo[(t + 1) & 1]);
         __syncthreads();
     }
+    // (halo[1] now holds the v_value plane: its depthwise conv goes straight out, from the wave the column phase leaves idle)
 
     // ---- columns: thread = (patch, kx): forward, recombine, inverse ---------------------------
     if (tid < NP * 5) {
@@ -219,6 +216,20 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
             S[(0 * NP + pj) * PS + kx * KXS + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
             S[(1 * NP + pj) * PS + kx * KXS + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
             S[(2 * NP + pj) * PS + kx * KXS + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
+        }
+    } else if (tid >= 192) {
+        // the 160 column jobs fill waves 0-2; wave 3 runs the v_value path of the whole tile meanwhile: four (patch, row) jobs per lane
+        float wk[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wk[i] = dww[(3 * E + e) * 9 + i];
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int J = (tid - 192) + 64 * i, pj = J >> 3, rj = J & 7;
+            const int pyj = pj >> 3, pxj = pj & 7;
+            const int gyj = ty0 + pyj * 8 + rj, gxj = tx0 + pxj * 8;
+            float o8[8];
+            stencil_row8(halo[1], pyj * 8 + rj, pxj * 8, wk, o8);
+            bstore8(o8, rout, (gyj < H && gxj < W) ? (unsigned)(gyj * W + gxj) * 4u : OOB, (unsigned)(3 * E + e) * hw4);
         }
     }
     __syncthreads();
