@@ -33,11 +33,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // erf, i.e. at fp32 rounding level on 1+erf), 1+erf formed without cancellation on the negative side.
 // ~12 VALU instructions instead of ~40 for erff.
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = x * 0.70710678118654752440f, az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float pe = poly * __expf(-az * az);
-    return 0.5f * x * (z >= 0.f ? 2.0f - pe : pe);
+    // 0.5 x erfc(-x / sqrt 2) with erfc(z) = t (a1 + t (a2 + ...)) e^{-z^2}, t = 1 / (1 + p z), z = |x| / sqrt 2: the scale of z is
+    // folded into p and into the exponent (e^{-x^2/2} = 2^{-(k x)^2}, k^2 = log2(e) / 2), the 0.5 into the coefficients: 15
+    // instructions, two of them transcendental (v_rcp_f32, v_exp_f32)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
+    const float poly = t * (0.5f * 0.254829592f + t * (0.5f * -0.284496736f + t * (0.5f * 1.421413741f + t * (0.5f * -1.453152027f + t * (0.5f * 1.061405429f)))));
+    const float u = x * 0.84932180028801904272f;                      // sqrt(log2(e) / 2)
+    const float pe = poly * __builtin_amdgcn_exp2f(-(u * u));         // 0.5 erfc(|x| / sqrt 2)
+    return x * (x >= 0.f ? 1.0f - pe : pe);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -526,9 +526,12 @@ struct FusedArgs {
     int E, H, W, tiles_x, tiles_per_img, nchunks;
 };
 
+#ifndef FDN_FUSED_WGS
+#define FDN_FUSED_WGS 2
+#endif
 template <int C, bool LN, bool OBF>          // OBF: the (out1|out2|out3|v_value) planes are stored as bf16
-__global__ __launch_bounds__(256, 2) void fdsa_fused_kernel(FusedArgs a) {
-    __shared__ float hid[32 * FPL];
+__global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArgs a) {
+    __shared__ float hid[32 * FPL + (FDN_FUSED_WGS == 1 ? 2048 : 0)];      // (A/B hook: a pad that leaves room for one workgroup per CU only)
     __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
     __shared__ float wks[32 * 9];                                     // depthwise taps of the chunk: [kind * 8 + channel][9]
     __shared__ float fgs[FEG * 40];                                   // fft gains of the chunk's channels: [channel][ky][kx]
