@@ -630,15 +630,12 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     // (C >= 48: the strips alone take 108 / 144 registers, so the A operands are not held across the spectral phases - they are
     //  fetched at the top of each chunk's MFMA phase, from L2, and the other workgroup of the CU covers the wait)
     constexpr bool AW_AHEAD = KS <= 7;
-    if (AW_AHEAD) aw_fetch(0);
-    stage_fetch(0);
-    stage_store();                      // (visible behind the first barrier of the loop)
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-        const int e0 = ch * FEG;
-        const int e = e0 + el;
+    // ---- to_hidden of one chunk on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes (0 outside the image: the
+    // strip, its statistics and `xone` all read 0 there).  With ROT the phase of chunk ch + 1 is issued in front of chunk ch's inverse rows
+    // (hid is free behind the column phase, the two share no data): the matrix pipe works under that phase's vector instructions
+    // instead of in a phase of its own (a wave issues in order: 39 MFMAs in a row kept its vector ALU idle for 11 % of the kernel)
+    auto mfma_phase = [&](int ch) __attribute__((always_inline)) {
         if (!AW_AHEAD) aw_fetch(ch);
-        // ---- to_hidden on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes (0 outside the image: the
-        // strip, its statistics and `xone` all read 0 there)
 #pragma unroll
         for (int si = 0; si < 3; ++si) {
 #ifdef FDN_KOF_MFMA
@@ -659,11 +656,21 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                 for (int r = 0; r < 16; ++r) hid[((r & 3) + 8 * (r >> 2) + 4 * kh) * FPL + pixoff[si]] = acc[r];   // row = kind * 8 + channel
             }
         }
+        if (AW_AHEAD && ch + 1 < a.nchunks) aw_fetch(ch + 1);
+    };
+    if (AW_AHEAD) aw_fetch(0);
+    stage_fetch(0);
+    stage_store();                      // (visible behind the first barrier of the loop)
+    // (measured, tools/ab_libs.py: the overlapped placement wins at C = 64, 1.41 against 1.45 ms - 25 MFMAs per strip - and loses at
+    //  C = 32, 2.47 against 2.36 ms - 13 per strip, and the accumulators then live across the inverse rows)
+    constexpr bool ROT = KST >= 3;
+    if (ROT) mfma_phase(0);
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const int e0 = ch * FEG;
+        const int e = e0 + el;
         const bool more = ch + 1 < a.nchunks;                       // uniform
-        if (more) {
-            if (AW_AHEAD) aw_fetch(ch + 1);
-            stage_fetch(ch + 1);
-        }
+        if (!ROT) mfma_phase(ch);
+        if (more) stage_fetch(ch + 1);
         __syncthreads();
 
         // ---- rows: depthwise 3x3 (to_hidden_dw, FDN_arch.py:578) + forward row transforms of q, k, v (v_value: see the column phase)
@@ -769,6 +776,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         }
         __syncthreads();
 
+        if (ROT && more) mfma_phase(ch + 1);       // writes hid (free behind the barrier above); overlaps the inverse rows below
         // ---- inverse rows, 32-byte segments straight to global (out1|out2|out3) --------------------------------------
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -782,9 +790,8 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
 #endif
             st_store8<OBF>(r8, rout, e < E ? opix + (unsigned)(t * E + e) * hwo : OOB, 0);
         }
-        if (more) stage_store();        // taps (last read before the second barrier) and gains (before the third) of the next chunk
-        // (the next chunk's MFMA phase writes `hid`, free since the second barrier; its row phase rewrites S behind
-        //  the barrier that follows the MFMA phase, i.e. after every thread has finished these reads)
+        if (more) stage_store();        // taps and gains of the next chunk (this chunk's were last read before the third barrier)
+        // (the next chunk's row phase rewrites S behind the barrier at the top of the loop, i.e. after every thread has finished these reads)
     }
 }
 
