@@ -351,7 +351,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-GPU batch is split over (measured best: 3)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the per-GPU batch is split over; > 1 is for experiments only: kernels of different "
+                    "streams that overlap a bf16-MFMA kernel return wrong rows on MI355X / ROCm 7.2 (DESIGN.md 4.7), 1 is the product path")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = BASELINE.json configs[1] (the reference's arithmetic); bf16 = configs[2]: bf16 STORAGE of the "
                          "block-internal activations between kernels, fp32 math / FFT / residual stream (DESIGN.md)")
@@ -420,7 +421,7 @@ def main():
         net, lp = build_models(dev, a.variant)
         x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
         mk = lambda r: make_input(a.batch, a.height, a.width, dev, seed=1000 + r)
-        forward = lambda t: forward_streams(net, lp, t, a.streams)     # LPNet -> FDN, sub-batches on separate HIP streams
+        forward = lambda t: forward_streams(net, lp, t, a.streams)     # LPNet -> FDN on one stream (--streams > 1: experiments, see above)
         if a.graph:
             from fdn_hip.pipeline import GraphedStep
             forward = GraphedStep(net, lp, a.streams)

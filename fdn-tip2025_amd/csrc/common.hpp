@@ -208,6 +208,10 @@ __device__ __forceinline__ fdn_f32x16 fdn_mfma_bf16(fdn_u32x4 a, fdn_u32x4 b, fd
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// NOTE (MI355X, ROCm 7.2): a kernel that issues v_mfma_f32_32x32x16_bf16 must not share the GPU with kernels of
+// ANOTHER HIP stream - the neighbours (this library's row FFT, rocFFT, a channel LayerNorm) then return wrong rows in up to half of
+// their launches; a compiler-generated loop of nothing but those MFMAs is enough (tools/cross_stream_probe.py), fp32 MFMA and
+// vector-ALU neighbours are harmless.  Hence one stream per GPU for this path (fdn_hip/pipeline.py).
 // the six leading products of one 16-deep k-step, small terms first
 __device__ __forceinline__ fdn_f32x16 fdn_mfma_split6(const fdn_u32x4 (&a)[3], const fdn_u32x4 (&b)[3], fdn_f32x16 c) {
     c = fdn_mfma_bf16(a[2], b[0], c);

@@ -398,9 +398,20 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
             }
         };
         ring_segment(tid);                                        // 256 of the 272 segments
-        if (tid < 16) ring_segment(256 + tid);
-        else if (tid < 16 + 2 * (TH + 2)) {                       // columns 64, 65 of every ring row
-            const int i = tid - 16, r = i >> 1, cc = 64 + (i & 1);
+        // what is left of the ring - segments 256..271 (128 pixels) and columns 64, 65 of every row (68) - goes out ONE PIXEL per
+        // thread to 196 threads of all four waves: as whole segments on threads 0-15 plus single pixels on the next 68 it kept
+        // wave 0 busy for ~290 more instructions than waves 2 and 3, and the barrier below waits for the slowest wave
+        if (tid < 128 + 2 * (TH + 2)) {
+            int r, cc;
+            if (tid < 128) {
+                const int job = 256 + (tid >> 3);
+                r = job % (TH + 2);
+                cc = (job / (TH + 2)) * 8 + (tid & 7);
+            } else {
+                const int i = tid - 128;
+                r = i >> 1;
+                cc = 64 + (i & 1);
+            }
             const int y = ty0 - 1 + r, xx = tx0 - 1 + cc;
             float a = 0.f;
             if (y >= 0 && y < H && xx >= 0 && xx < W) {
@@ -408,7 +419,9 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) a = fmaf(k0[dy * 3 + dx], tin[(r + dy) * LS2 + cc + dx], a);
+#ifndef FDN_KO_GELU
                 a = gelu_fast(a);
+#endif
             }
             mid[r * LSM + cc] = a;
         }
@@ -553,7 +566,8 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     // parts (common.hpp: fp32 arithmetic on the bf16 matrix pipe); channels k >= C read 0 and meet zero weights.
     constexpr int KST = (C + 15) / 16;
     fdn_u32x4 xb[3][KST][3];
-    fdn_u32x4 xone[3];                  // B operand of the bias step: bf16 1.0 on k = 0, 1, 2 (the bias' three parts) inside the image
+    unsigned onebits = 0;               // bit si: B operand of the bias step is bf16 1.0 on k = 0, 1, 2 (the bias' three parts): this
+                                        // lane is in the lower half and its pixel of strip si lies inside the image
     int pixoff[3];
 #pragma unroll
     for (int si = 0; si < 3; ++si) {
@@ -563,8 +577,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
         const bool in_tile = s < FNS && p < FHP;
         const bool ok = in_tile && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const bool one = ok && kh == 0;
-        xone[si] = fdn_u32x4{one ? 0x3F803F80u : 0u, one ? 0x00003F80u : 0u, 0u, 0u};
+        onebits |= (ok && kh == 0) ? (1u << si) : 0u;
         pixoff[si] = in_tile ? r * FRS + c : FHW;                 // lanes past the tile: the unused pad cell of row 0 of each plane
         const unsigned g = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
         float mu = 0.f, rs = 1.f;
@@ -601,11 +614,12 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     // `xone`): registers, reloaded for the NEXT chunk right after this chunk's MFMAs so the loads fly during the spectral
     // phases.  Depthwise taps and fft gains: one element per thread, staged through LDS a chunk ahead.
     constexpr int KS = KST * 3 + 1;
-    fdn_u32x4 aw[KS];
+    constexpr bool AW_AHEAD = KS <= 7;
+    fdn_u32x4 aw[AW_AHEAD ? KS : 1];
     auto aw_fetch = [&](int ch) {
         const fdn_u32x4* wp = reinterpret_cast<const fdn_u32x4*>(a.wpk) + ((long)ch * KS) * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) aw[j] = wp[j * 64];
+        for (int j = 0; j < (AW_AHEAD ? KS : 1); ++j) aw[j] = wp[j * 64];
     };
     float st_w = 0.f, st_w1 = 0.f, st_f0 = 0.f, st_f1 = 0.f;
     auto stage_fetch = [&](int ch) {
@@ -627,15 +641,15 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         fgs[tid] = st_f0;
         if (tid < 64) fgs[tid + 256] = st_f1;
     };
-    // (C >= 48: the strips alone take 108 / 144 registers, so the A operands are not held across the spectral phases - they are
-    //  fetched at the top of each chunk's MFMA phase, from L2, and the other workgroup of the CU covers the wait)
-    constexpr bool AW_AHEAD = KS <= 7;
+    // (C >= 48: the strips alone take 108 / 144 registers, so the A operands are not held in registers at all - each k-step reads its
+    //  three fragments from L1 / L2 - and no instantiation spills: 1.43 ms against 1.53-1.56 ms at level 2 for the variants that hold
+    //  them in registers and spill 14-18, tools/ab_libs.py)
     // ---- to_hidden of one chunk on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes (0 outside the image: the
     // strip, its statistics and `xone` all read 0 there).  With ROT the phase of chunk ch + 1 is issued in front of chunk ch's inverse rows
     // (hid is free behind the column phase, the two share no data): the matrix pipe works under that phase's vector instructions
     // instead of in a phase of its own (a wave issues in order: 39 MFMAs in a row kept its vector ALU idle for 11 % of the kernel)
     auto mfma_phase = [&](int ch) __attribute__((always_inline)) {
-        if (!AW_AHEAD) aw_fetch(ch);
+        const fdn_u32x4* wp_ = reinterpret_cast<const fdn_u32x4*>(a.wpk) + ((long)ch * KS) * 64 + lane;      // (!AW_AHEAD: operands straight from L1 / L2)
 #pragma unroll
         for (int si = 0; si < 3; ++si) {
 #ifdef FDN_KOF_MFMA
@@ -647,13 +661,25 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
+#ifdef FDN_KOF_NOMFMA
+                for (int ks = 0; ks < KST; ++ks)
+                    for (int r = 0; r < 16; ++r) acc[r] += __uint_as_float(aw[3 * ks][r & 3]) * __uint_as_float(xb[si][ks][r % 3][r >> 2]);
+#else
                 for (int ks = 0; ks < KST; ++ks) {
-                    const fdn_u32x4 a3[3] = {aw[3 * ks], aw[3 * ks + 1], aw[3 * ks + 2]};
+                    const fdn_u32x4 a3[3] = {AW_AHEAD ? aw[3 * ks] : wp_[(3 * ks) * 64], AW_AHEAD ? aw[3 * ks + 1] : wp_[(3 * ks + 1) * 64],
+                                             AW_AHEAD ? aw[3 * ks + 2] : wp_[(3 * ks + 2) * 64]};
                     acc = fdn_mfma_split6(a3, xb[si][ks], acc);
                 }
-                acc = fdn_mfma_bf16(aw[KS - 1], xone[si], acc);      // + bias: b1 + b2 + b3 against 1, 1, 1 (0 outside the image)
+#endif
+                const bool one = (onebits >> si) & 1u;
+                const fdn_u32x4 xone = {one ? 0x3F803F80u : 0u, one ? 0x00003F80u : 0u, 0u, 0u};
+                acc = fdn_mfma_bf16(AW_AHEAD ? aw[KS - 1] : wp_[(KS - 1) * 64], xone, acc);          // + bias: b1 + b2 + b3 against 1, 1, 1 (0 outside the image)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hid[((r & 3) + 8 * (r >> 2) + 4 * kh) * FPL + pixoff[si]] = acc[r];   // row = kind * 8 + channel
+                for (int r = 0; r < 16; ++r)
+#ifdef FDN_KOF_NOHID
+                    if (acc[0] == 123.456f)
+#endif
+                    hid[((r & 3) + 8 * (r >> 2) + 4 * kh) * FPL + pixoff[si]] = acc[r];   // row = kind * 8 + channel
             }
         }
         if (AW_AHEAD && ch + 1 < a.nchunks) aw_fetch(ch + 1);
@@ -663,7 +689,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     stage_store();                      // (visible behind the first barrier of the loop)
     // (measured, tools/ab_libs.py: the overlapped placement wins at C = 64, 1.41 against 1.45 ms - 25 MFMAs per strip - and loses at
     //  C = 32, 2.47 against 2.36 ms - 13 per strip, and the accumulators then live across the inverse rows)
-    constexpr bool ROT = KST >= 3;
+    constexpr bool ROT = false;
     if (ROT) mfma_phase(0);
     for (int ch = 0; ch < a.nchunks; ++ch) {
         const int e0 = ch * FEG;
@@ -724,8 +750,11 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
 #pragma unroll
             for (int ky = 0; ky < 8; ++ky) fg[ky] = fgs[(pj >> 2) * 40 + ky * 5 + kx];
             fft8<false>(q);
+            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             fft8<false>(k);
+            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             fft8<false>(v);
+            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             float2 o1[8], o2[8], o3[8];
 #ifdef FDN_KOF_RECOMB
             for (int ky = 0; ky < 8; ++ky) { o1[ky] = q[ky]; o2[ky] = k[ky]; o3[ky] = make_float2(v[ky].x * fg[ky], v[ky].y); }
@@ -749,9 +778,12 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                 o1[ky] = make_float2(va * u.x, va * u.y);                                     // :609-612
                 o2[ky] = make_float2(g * v1.x, g * v1.y);                                     // :617-619
                 o3[ky] = make_float2(qka * u.x, qka * u.y);                                   // :627-629
+                if (KST >= 4) __builtin_amdgcn_sched_barrier(0);     // C = 64 (144 registers of strips): one bin at a time, or the kernel spills
             }
             fft8<true>(o1);
+            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             fft8<true>(o2);
+            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             fft8<true>(o3);
             constexpr float sc = 1.0f / 64.0f;   // norm='backward'
 #pragma unroll

@@ -77,7 +77,7 @@ def enhance_u8(net, lpnet, img_u8, bgr=True, ratio_mode="lolblur"):
     x, h, w = preprocess(img_u8, bgr=bgr)
     if ratio_mode == "lolblur":
         from .pipeline import run
-        result = run(net, lpnet, x)                # hipGraph replay for small frames, HIP streams for large batches
+        result = run(net, lpnet, x)                # hipGraph replay for small frames, the eager forward otherwise
     else:
         ratio = lolv1_ratio(x, lpnet(x))
         result = net(x, ratio_i=ratio, device=x.device)[0]

@@ -1,10 +1,17 @@
 """Batch-level execution helpers for the FDN path (host side, no compute of their own).
 
 Images never interact inside LPNet -> FDN, so a batch can be cut into independent
-sub-batches.  `forward_streams` runs the sub-batches on separate HIP streams of one GPU: the MFMA-bound
-level-2/3 GEMMs of one sub-batch overlap the HBM-bound stencil / FFT kernels of the other
-(+5 % images/s at B = 8 on MI355X, bit-identical outputs).  Multi-GPU sharding (one process per GPU)
-is the same cut one level up, see bench.py.
+sub-batches.  Multi-GPU sharding (one process per GPU, bench.py) is that cut; ONE stream per GPU is the
+rule inside a process.
+
+`forward_streams(..., n_streams > 1)` - sub-batches on separate HIP streams of one GPU, +1.3 % images/s at
+B = 8 since the 1x1 convs moved to the bf16 matrix pipe - is kept for experiments only and is NOT used by
+`run`, bench.py or the tests' reference paths: on MI355X / ROCm 7.2 a kernel issuing
+v_mfma_f32_32x32x16_bf16 corrupts kernels of OTHER streams that share the GPU with it (wrong rows in up
+to half of the neighbour's launches; rocFFT is hit as well as this library's kernels, and a loop of
+nothing but compiler-generated MFMAs is enough to trigger it: tools/cross_stream_probe.py,
+profiles/r03_cross_stream_probe.txt).  Within one stream kernels never overlap and the
+outputs are bit-stable (tests/test_gpu_edge.py::test_single_stream_bit_stable).
 """
 import collections
 
@@ -22,8 +29,9 @@ def _get_streams(device, n):
     return _streams[key]
 
 
-def forward_streams(net, lpnet, x, n_streams=2):
-    """result = FDN(x, ratio_i=LPNet(x))[0] with the batch split over `n_streams` HIP streams."""
+def forward_streams(net, lpnet, x, n_streams=1):
+    """result = FDN(x, ratio_i=LPNet(x))[0]; n_streams > 1 splits the batch over HIP streams (see the module note: not
+    bit-stable on MI355X / ROCm 7.2, experiments only)."""
     B = x.shape[0]
     if n_streams <= 1 or B < n_streams:
         with torch.no_grad():
@@ -108,11 +116,12 @@ class GraphedForward:
 
 
 class GraphedStep:
-    """forward_streams (every sub-batch stream) captured into ONE HIP graph for a fixed input shape and replayed: the ~2,400
-    launches of a B = 8 720p step become one hipGraphLaunch, which takes the Python launch work off the host - what matters
-    when eight ranks share one host (bench.py --graph).  The result tensor is overwritten by the next call."""
+    """One whole step (forward_streams, every sub-batch stream if there are several) captured into ONE HIP graph for a fixed
+    input shape and replayed: the ~2,400 launches of a B = 8 720p step become one hipGraphLaunch, which takes the Python launch
+    work off the host - what matters when eight ranks share one host (bench.py --graph).  The result tensor is overwritten by
+    the next call."""
 
-    def __init__(self, net, lpnet, n_streams=3):
+    def __init__(self, net, lpnet, n_streams=1):
         self.net, self.lpnet, self.n = net, lpnet, n_streams
         self._g = None
 
@@ -133,14 +142,14 @@ class GraphedStep:
 GRAPH_BELOW_PIXELS = 1 << 20          # B*H*W under which a forward is launch-bound (256 x 256: 23 ms eager vs ~6 ms of kernels)
 
 
-def run(net, lpnet, x, n_streams=3):
-    """The default way to run LPNet -> FDN on one GPU: hipGraph replay for small inputs (launch-bound) whose shape recurs,
-    sub-batches on `n_streams` HIP streams for large ones.  Returns result [B,3,H,W] (valid until the next call for the graph path).
-    The GraphedForward lives on the model object (it dies with it)."""
+def run(net, lpnet, x):
+    """The default way to run LPNet -> FDN on one GPU: hipGraph replay for small inputs (launch-bound) whose shape recurs, the
+    eager forward on the caller's stream for large ones.  Returns result [B,3,H,W] (valid until the next call for the graph
+    path).  The GraphedForward lives on the model object (it dies with it)."""
     B, _, H, W = x.shape
     if B * H * W < GRAPH_BELOW_PIXELS:
         g = net.__dict__.get("_fdn_graphed")
         if g is None or g.lpnet is not lpnet:
             g = net.__dict__["_fdn_graphed"] = GraphedForward(net, lpnet)
         return g(x)
-    return forward_streams(net, lpnet, x, n_streams)
+    return forward_streams(net, lpnet, x, 1)
