@@ -227,24 +227,35 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
     __syncthreads();
     const float invE = 1.0f / (float)E;
 
+    constexpr unsigned IES = st_bytes<IBF>();
+    const unsigned PI = P * IES;                              // bytes per `o` plane
+    // tile -> image, pixel pair of this lane, descriptor of group g's E planes
+    auto tile_b = [&](int tile) { return tile / a.tiles_per_img; };
+    auto tile_p = [&](int tile, int b) { return (unsigned)(tile - b * a.tiles_per_img) * (NW * 64) + (wave * 32 + ln) * 2; };
+    auto oplanes = [&](int b, int g) {
+        const char* ob = reinterpret_cast<const char*>(a.o) + (long)b * 4 * E * P * IES;
+        return mk_rsrc(reinterpret_cast<const float*>(ob + (long)g * E * P * IES), (unsigned)E * PI);
+    };
+    f32x2 vv[SH], oa[SH], ob2[DB ? SH : 1];
+    bool fetched = false;                                     // DB: v_value and group 0 of this tile were requested by the previous tile
     for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-        const int b = tile / a.tiles_per_img;
-        const unsigned p_ = (unsigned)(tile - b * a.tiles_per_img) * (NW * 64) + (wave * 32 + ln) * 2;
+        const int b = tile_b(tile);
+        const unsigned p_ = tile_p(tile, b);
         const bool ok = p_ < P;                               // P % 2 == 0: a pixel pair is inside or outside as a whole
         const unsigned pix = ok ? p_ : P - 2;
-        constexpr unsigned IES = st_bytes<IBF>();
-        const unsigned PI = P * IES;                          // bytes per `o` plane
-        const char* ob = reinterpret_cast<const char*>(a.o) + (long)b * 4 * E * P * IES;
-        auto oplanes = [&](int g) { return mk_rsrc(reinterpret_cast<const float*>(ob + (long)g * E * P * IES), (unsigned)E * PI); };
-        const rsrc_t rg[3] = {oplanes(0), oplanes(1), oplanes(2)};
-        const rsrc_t rv = oplanes(3);
+        const rsrc_t rg[3] = {oplanes(b, 0), oplanes(b, 1), oplanes(b, 2)};
+        const rsrc_t rv = oplanes(b, 3);
         const unsigned voff = (kh * P + pix) * IES;          // channel e = 2s + kh; e >= E reads 0 (outside the descriptor)
 
-        f32x2 vv[SH], oa[SH], ob2[DB ? SH : 1];
+        if (DB && fetched) {
 #pragma unroll
-        for (int s = 0; s < SH; ++s) {
-            vv[s] = oload2<IBF>(rv, voff, (unsigned)(2 * s) * PI);
-            oa[s] = oload2<IBF>(rg[0], voff, (unsigned)(2 * s) * PI);
+            for (int s = 0; s < (DB ? SH : 1); ++s) oa[s] = ob2[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < SH; ++s) {
+                vv[s] = oload2<IBF>(rv, voff, (unsigned)(2 * s) * PI);
+                oa[s] = oload2<IBF>(rg[0], voff, (unsigned)(2 * s) * PI);
+            }
         }
         const unsigned nb4 = (unsigned)N * P4;
         const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
@@ -287,6 +298,23 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
                 asm volatile("" ::: "memory");                              // table reads stay here (registers)
                 const int e = 2 * s + kh;
                 cur[s] = ((cur[s] - m) * rs * tg[g * E2 + e] + tb[g * E2 + e]) * vv[s];      // norm_g(out_g) * v_value  :633-638
+            }
+            if (DB && g == 2) {
+                // the NEXT tile's v_value and group 0 go into the two register sets that are dead from here (v_value was last used
+                // just above, the idle set holds group 1): their round trip hides behind this tile's last MFMAs and its epilogue
+                const int nt = tile + (int)gridDim.x;
+                fetched = nt < a.total_tiles;
+                if constexpr (DB) if (fetched) {
+                    const int nb = tile_b(nt);
+                    const unsigned np_ = tile_p(nt, nb);
+                    const unsigned nvoff = (kh * P + (np_ < P ? np_ : P - 2)) * IES;
+                    const rsrc_t nrv = oplanes(nb, 3), nr0 = oplanes(nb, 0);
+#pragma unroll
+                    for (int s = 0; s < SH; ++s) {
+                        vv[s] = oload2<IBF>(nrv, nvoff, (unsigned)(2 * s) * PI);
+                        ob2[s] = oload2<IBF>(nr0, nvoff, (unsigned)(2 * s) * PI);
+                    }
+                }
             }
             if (DB && g == 2) {      // (level 2 has no idle set: requested ahead it spills 39 registers, so it stays in the epilogue there)
                 // the residual is requested here: v_value (and, with DB, the idle register set) is dead from this point, and the

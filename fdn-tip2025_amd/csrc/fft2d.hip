@@ -260,7 +260,9 @@ __device__ void fft_pass_reg(const float2* src, float2* dst, int N, int Ns, int 
     }
 }
 
-template <bool INV, bool BIG>
+// BIG: 0 = register butterflies for the radices 2-7 only, 1 = + 17 / 23 (1080p / 720p lengths), 2 = + 37 / 41 (the (H + 2)-row
+// maps of fourier_fuse: 738 = 41 * 18, 370 = 37 * 10) - tiers, because the widest butterfly sets the kernel's register count
+template <bool INV, int BIG>
 __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, int nseq, int ss, int es, bool seq_fast,
                          const float2* __restrict__ tw, int tab_mul) {
     const int T = N / R;
@@ -274,6 +276,8 @@ __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, i
         case 7: fft_pass_reg<INV, 7>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
         case 17: if (BIG) { fft_pass_reg<INV, 17>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
         case 23: if (BIG) { fft_pass_reg<INV, 23>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
+        case 37: if (BIG == 2) { fft_pass_reg<INV, 37>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
+        case 41: if (BIG == 2) { fft_pass_reg<INV, 41>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
         default: break;
     }
     if (R != 2 && R != 4) {
@@ -337,7 +341,7 @@ __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, i
 }
 
 // run all passes; returns the buffer holding the result
-template <bool INV, bool BIG>
+template <bool INV, int BIG>
 __device__ float2* fft_run(float2* a, float2* b, const Plan& p, const float2* tw, int nseq, int ss, int es, bool seq_fast) {
     int Ns = 1;
     float2* src = a;
@@ -417,7 +421,7 @@ __device__ void fft_pass_inplace(float2* buf, int N, int Ns, int nseq, const flo
     __syncthreads();
 }
 
-template <bool INV, bool BIG>
+template <bool INV, int BIG>
 __device__ void fft_run_inplace(float2* buf, const Plan& p, const float2* tw, int nseq) {
     int Ns = 1;
     __syncthreads();
@@ -684,7 +688,7 @@ struct ColArgs {
 
 enum { COL_FCAFFN = 0, COL_FWD = 1, COL_INV_POLAR = 2 };
 
-template <int MODE, bool BIG, bool INPL>
+template <int MODE, int BIG, bool INPL>
 __global__ __launch_bounds__(NT, (INPL ? 2 : 1)) void fft_cols_kernel(ColArgs a, const Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = a.H, Wf = a.Wf, tc = a.tc;
@@ -1129,6 +1133,11 @@ bool plan_big(const Plan& p) {
         if (p.radix[i] == 17 || p.radix[i] == 23) return true;
     return false;
 }
+bool plan_big2(const Plan& p) {
+    for (int i = 0; i < p.nst; ++i)
+        if (p.radix[i] == 37 || p.radix[i] == 41) return true;
+    return false;
+}
 
 int pick_tc(int H) {
     const long per_col = 2L * H * sizeof(float2);
@@ -1166,7 +1175,7 @@ int inplace_tc(const Plan& p, int H) {
     return 0;
 }
 
-template <int MODE, bool BIG, bool INPL>
+template <int MODE, int BIG, bool INPL>
 int launch_cols_k(ColArgs a, const Plan& p, long planes, size_t lds, fdn_stream_t stream) {
     a.planes = planes;
     if (a.C <= 0 || planes % a.C != 0) a.C = 1;
@@ -1192,15 +1201,16 @@ int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
         a.tc = itc;
         a.tcs = __builtin_ctz(itc);
         const size_t lds = ((size_t)a.H * a.tc + a.H) * sizeof(float2);
-        return plan_big(p) ? launch_cols_k<MODE, true, true>(a, p, planes, lds, stream)
-                           : launch_cols_k<MODE, false, true>(a, p, planes, lds, stream);
+        return plan_big(p) ? launch_cols_k<MODE, 1, true>(a, p, planes, lds, stream)
+                           : launch_cols_k<MODE, 0, true>(a, p, planes, lds, stream);
     }
     a.tc = pick_tc(a.H);
     if (a.tc == 0) return FDN_ERR_UNSUPPORTED;
     a.tcs = __builtin_ctz(a.tc);
     const size_t lds = (2UL * a.H * a.tc + a.H) * sizeof(float2);
-    return plan_big(p) ? launch_cols_k<MODE, true, false>(a, p, planes, lds, stream)
-                       : launch_cols_k<MODE, false, false>(a, p, planes, lds, stream);
+    if (plan_big2(p)) return launch_cols_k<MODE, 2, false>(a, p, planes, lds, stream);
+    return plan_big(p) ? launch_cols_k<MODE, 1, false>(a, p, planes, lds, stream)
+                       : launch_cols_k<MODE, 0, false>(a, p, planes, lds, stream);
 }
 
 // ------------------------------------------------------------------------------------------

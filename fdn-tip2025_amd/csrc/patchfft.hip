@@ -645,9 +645,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     //  three fragments from L1 / L2 - and no instantiation spills: 1.43 ms against 1.53-1.56 ms at level 2 for the variants that hold
     //  them in registers and spill 14-18, tools/ab_libs.py)
     // ---- to_hidden of one chunk on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes (0 outside the image: the
-    // strip, its statistics and `xone` all read 0 there).  With ROT the phase of chunk ch + 1 is issued in front of chunk ch's inverse rows
-    // (hid is free behind the column phase, the two share no data): the matrix pipe works under that phase's vector instructions
-    // instead of in a phase of its own (a wave issues in order: 39 MFMAs in a row kept its vector ALU idle for 11 % of the kernel)
+    // strip, its statistics and `xone` all read 0 there)
     auto mfma_phase = [&](int ch) __attribute__((always_inline)) {
         const fdn_u32x4* wp_ = reinterpret_cast<const fdn_u32x4*>(a.wpk) + ((long)ch * KS) * 64 + lane;      // (!AW_AHEAD: operands straight from L1 / L2)
 #pragma unroll
@@ -687,15 +685,14 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     if (AW_AHEAD) aw_fetch(0);
     stage_fetch(0);
     stage_store();                      // (visible behind the first barrier of the loop)
-    // (measured, tools/ab_libs.py: the overlapped placement wins at C = 64, 1.41 against 1.45 ms - 25 MFMAs per strip - and loses at
-    //  C = 32, 2.47 against 2.36 ms - 13 per strip, and the accumulators then live across the inverse rows)
-    constexpr bool ROT = false;
-    if (ROT) mfma_phase(0);
+    // (measured, tools/ab_libs.py: issuing the MFMA phase of chunk ch + 1 in front of chunk ch's inverse rows - the matrix pipe under
+    //  that phase's vector instructions - loses: 2.47 against 2.36 ms at C = 32, 1.46 against 1.42 ms at C = 64; the accumulators then
+    //  live across the inverse rows)
     for (int ch = 0; ch < a.nchunks; ++ch) {
         const int e0 = ch * FEG;
         const int e = e0 + el;
         const bool more = ch + 1 < a.nchunks;                       // uniform
-        if (!ROT) mfma_phase(ch);
+        mfma_phase(ch);
         if (more) stage_fetch(ch + 1);
         __syncthreads();
 
@@ -808,7 +805,6 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         }
         __syncthreads();
 
-        if (ROT && more) mfma_phase(ch + 1);       // writes hid (free behind the barrier above); overlaps the inverse rows below
         // ---- inverse rows, 32-byte segments straight to global (out1|out2|out3) --------------------------------------
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
