@@ -1,4 +1,5 @@
-// Dense 3x3 convolution (stride 1, zero pad 1) as implicit GEMM on fp32 MFMA: the FDformer's
+// Dense 3x3 convolution (stride 1, zero pad 1) as implicit GEMM on the matrix cores (a flat-pixel fp32-MFMA form for any
+// shape, an LDS-tiled split-bf16 form for Cin % 8 == 0 - fp32-exact to rounding, further down): the FDformer's
 // Downsample / Upsample convs (FDN_arch.py:720,731) and MAR's 3x3 convs (:57,:135,:174-175,:196).
 //
 // Same operand mapping as gemm1x1.hip: D[n][p] = sum_k' W[n][k'] * X[k'][p] with
@@ -165,29 +166,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv3x3_kernel(C3Arg
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// LDS-tiled form for Cin % 8 == 0 and Cout = 32 / 64 (the Downsample / Upsample body convs, 64 -> 32 at level 1 and
-// 128 -> 64 at level 2: 278 GFLOP each).  The flat-pixel kernel above loads every input value nine times from global memory
-// (once per tap, 5-6x the algorithmic HBM bytes once the in-flight tiles outgrow L2: profiles/r02_c_summary.txt); here a
-// workgroup owns an 8 x 32 output tile, stages the 10 x 34 halo tile of 8 input channels in LDS (zero-filled outside the
-// image, double buffered) and every MFMA B operand is an LDS read at a compile-time offset: (tap, channel pair) k-steps,
-// 36 per chunk.  A wave computes two rows (two 32-pixel strips) x all output channels, so each A operand read from LDS feeds
-// two MFMAs.  The weight rows of a chunk (72 x Cout, gathered from the checkpoint layout: 72 consecutive floats per output
-// channel) stream through the second half of the double buffer; one barrier per chunk of 144 x Cout/32 MFMAs per wave.
-// ------------------------------------------------------------------------------------------------
-constexpr int TH = 8, TW = 32, CK = 8, HR = TH + 2, HC = TW + 2;
-constexpr int PL = 352;                        // plane stride of the staged tile (340 used): = 32 mod 64, the two k of a step hit disjoint banks
-constexpr int KST = 9 * CK / 2;                // k-steps per chunk
+constexpr int TW = 32, CK = 8, HC = TW + 2;      // tile columns, input channels per chunk, halo columns
 
-template <int MT>
-__global__ __launch_bounds__(256, 2) void conv3x3_tiled_kernel(C3Args a, int tiles_x, int tiles_y) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int N = MT * 32, WS = N + 1;
-    constexpr int XB = CK * PL, WB = 9 * CK * WS;              // floats per buffer
-    constexpr int XE = (CK * HR * HC + 255) / 256;             // staged input elements per thread (11)
-    constexpr int WE = (9 * CK * N + 255) / 256;               // staged weight elements per thread
-    float* Xl = smem;                           // [2][CK][PL]
-    float* Wl = smem + 2 * XB;                  // [2][72][WS]
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled form for Cin % 8 == 0, Cout >= 16 (the Downsample / Upsample body convs, 64 -> 32 at level 1 and 128 -> 64 at level 2:
+// 278 GFLOP each; MAR's 24 -> 24 and 48 -> 48).  The flat-pixel kernel above loads every input value nine times from global
+// memory; here a workgroup owns a 2*NW x 32 output tile and stages the halo tile of 8 input channels in LDS (zero-filled outside
+// the image, double buffered, requested two chunks ahead).  Round 3: both operands are cut into three exact
+// bf16 parts WHEN THEY ARE STAGED - a value is split once and then read by all nine taps - and the six leading products of a
+// 16-deep k-step run on v_mfma_f32_32x32x16_bf16 (fp32 accumulate: fp32 accuracy, a quarter of the matrix-pipe cycles of
+// v_mfma_f32_32x32x2_f32, and the pipe is not the vector ALU's): 64 -> 32 2.70 -> 2.32 ms, 128 -> 64 2.64 -> 1.90 ms,
+// 24 -> 24 (was on the direct vector-ALU kernel) 0.89 -> 0.21 ms.  A k-step is TWO taps x
+// 8 channels: lane half kh reads tap 2 s + kh (its own (dy, dx) offset into the staged tile), k = 8 kh + channel; the tenth
+// tap of the fifth k-step has zero weights.  LDS holds, per buffer, the tile as [part][position] 16-byte cells (8 channels of
+// one pixel: one ds_read_b128 per part and row) and the weights as [k-step][part][channel tile][lane] cells in operand order.
+// Any Cout: channels past the tensor read zero weights and their rows fall outside the output descriptor.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && MT == 1) ? 2 : 1) void conv3x3_split_kernel(C3Args a, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) fdn_u32x4 smem4[];
+    constexpr int NT = NW * 64, TH_ = 2 * NW, HR_ = TH_ + 2, NPOS = HR_ * HC;
+    constexpr int N = MT * 32, KS5 = 5;
+    constexpr int XB = 3 * NPOS, WB = KS5 * 3 * MT * 64;      // cells per buffer
+    constexpr int XE = (NPOS + NT - 1) / NT;                   // staged pixel positions per thread
+    constexpr int WE = (N * 9 * CK + NT - 1) / NT;             // staged weights per thread (72 consecutive floats per output channel: coalesced)
+    fdn_u32x4* Xs = smem4;                      // [2][3][NPOS]
+    fdn_u32x4* Ws = smem4 + 2 * XB;             // [2][5][3][MT][64]
     const int Cin = a.Cin, H = a.H, W = a.W;
     const unsigned P = (unsigned)H * W, P4 = P * 4u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
@@ -195,51 +199,80 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tiled_kernel(C3Args a, int til
     int b, y0, x0;
     {
         const unsigned T = (unsigned)(tiles_x * tiles_y) * a.B;
-        const unsigned S0 = xcd_contiguous(blockIdx.x, gridDim.x);  // neighbouring tiles (shared halo rows / lines) on one XCD
-        const unsigned grp = S0 / T, S = S0 - grp * T;              // output-channel group of this workgroup (gridDim.x = groups * T)
+        const unsigned S0 = xcd_contiguous(blockIdx.x, gridDim.x);
+        const unsigned grp = S0 / T, S = S0 - grp * T;
         a.n0 = (int)grp * N;
         const unsigned per = (unsigned)(tiles_x * tiles_y);
         b = (int)(S / per);
         const unsigned t = S - (unsigned)b * per;
         const int ty = (int)(t / (unsigned)tiles_x);
-        y0 = ty * TH;
+        y0 = ty * TH_;
         x0 = (int)(t - (unsigned)ty * tiles_x) * TW;
     }
-    // staging plan of this thread: the same positions for every chunk, only the channel base moves
-    unsigned xg[XE];                            // global byte offset inside the 8-channel slab (0x80000000 = outside the image: reads 0)
-    int xl[XE];                                 // LDS float offset, -1 = no element
+    const int nvalid = min(N, a.CoutT - a.n0);                 // output channels of this group that exist
+    unsigned xg[XE];
+    int xl[XE];
 #pragma unroll
     for (int i = 0; i < XE; ++i) {
-        const int e = tid + 256 * i;
-        const int ci = e / (HR * HC), q = e - ci * (HR * HC), r = q / HC, c = q - r * HC;
+        const int e = tid + NT * i, r = e / HC, c = e - r * HC;
         const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        const bool in = e < CK * HR * HC, ok = in && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        xg[i] = ok ? ((unsigned)ci * P + (unsigned)(gy * W + gx)) * 4u : 0x80000000u;
-        xl[i] = in ? ci * PL + r * HC + c : -1;
+        const bool in = e < NPOS, ok = in && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        xg[i] = ok ? (unsigned)(gy * W + gx) * 4u : 0x80000000u;
+        xl[i] = in ? e : -1;
     }
     const rsrc_t rx = mk_rsrc(a.x + (long)b * Cin * P, (unsigned)Cin * P4);
-    float xr[XE], wr[WE];
-    auto fetch = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < XE; ++i) xr[i] = bload(rx, xg[i], (unsigned)(c * CK) * P4);
-#pragma unroll
-        for (int i = 0; i < WE; ++i) {
-            const int e = tid + 256 * i, n = e / (9 * CK), q = e - n * (9 * CK);      // 72 consecutive floats per output channel
-            wr[i] = (e < 9 * CK * N) ? a.w[((long)(a.n0 + n) * Cin + c * CK) * 9 + q] : 0.f;
-        }
-    };
-    auto stash = [&](int buf) __attribute__((always_inline)) {
-        float* xd = Xl + buf * XB;
+    // two register stages: chunk c + 2 is requested while chunk c is multiplied (a chunk is ~1 us of matrix work, an HBM round trip
+    // under load is longer), and parked in LDS a chunk later
+    struct Stage { float xr[XE][CK], wr[WE]; };
+    Stage stg[2];
+    auto fetch = [&](int c, Stage& sg) __attribute__((always_inline)) {
+        float (&xr)[XE][CK] = sg.xr;
+        float (&wr)[WE] = sg.wr;
 #pragma unroll
         for (int i = 0; i < XE; ++i)
-            if (xl[i] >= 0) xd[xl[i]] = xr[i];
-        float* wd = Wl + buf * WB;
+#pragma unroll
+            for (int ci = 0; ci < CK; ++ci) xr[i][ci] = bload(rx, xg[i], (unsigned)(c * CK + ci) * P4);
 #pragma unroll
         for (int i = 0; i < WE; ++i) {
-            const int e = tid + 256 * i, n = e / (9 * CK), q = e - n * (9 * CK), ci = q / 9, tap = q - ci * 9;
-            if (e < 9 * CK * N) wd[(tap * CK + ci) * WS + n] = wr[i];                 // row k' = tap * 8 + ci
+            const int e = tid + NT * i, n = e / (9 * CK), q = e - n * (9 * CK);
+            wr[i] = (e < N * 9 * CK && n < nvalid) ? a.w[((long)(a.n0 + n) * Cin + c * CK) * 9 + q] : 0.f;
         }
     };
+    auto stash = [&](int buf, const Stage& sg) __attribute__((always_inline)) {
+        const float (&xr)[XE][CK] = sg.xr;
+        const float (&wr)[WE] = sg.wr;
+        fdn_u32x4* xd = Xs + buf * XB;
+#pragma unroll
+        for (int i = 0; i < XE; ++i) {
+            fdn_u32x4 p1, p2, p3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned u1, u2, u3;
+                fdn_split3(xr[i][2 * j], xr[i][2 * j + 1], u1, u2, u3);
+                p1[j] = u1; p2[j] = u2; p3[j] = u3;
+            }
+            if (xl[i] >= 0) {
+                xd[xl[i]] = p1;
+                xd[NPOS + xl[i]] = p2;
+                xd[2 * NPOS + xl[i]] = p3;
+            }
+        }
+        // a weight (n, ci, tap) is one bf16 of the cell (k-step tap / 2, lane half tap % 2, lane n): three 16-bit stores, no pairing
+        unsigned short* wd = reinterpret_cast<unsigned short*>(Ws + buf * WB);
+#pragma unroll
+        for (int i = 0; i < WE; ++i) {
+            const int e = tid + NT * i, n = e / (9 * CK), q = e - n * (9 * CK), ci = q / 9, tap = q - ci * 9;
+            const int cell = (n >> 5) * 64 + (tap & 1) * 32 + (n & 31), s_ = tap >> 1;
+            const float w1 = fdn_trunc_bf16(wr[i]), r1 = wr[i] - w1, w2 = fdn_trunc_bf16(r1), w3 = r1 - w2;
+            if (e < N * 9 * CK && n < nvalid) {
+                wd[((s_ * 3 + 0) * (MT * 64) + cell) * 8 + ci] = (unsigned short)(__float_as_uint(w1) >> 16);
+                wd[((s_ * 3 + 1) * (MT * 64) + cell) * 8 + ci] = (unsigned short)(__float_as_uint(w2) >> 16);
+                wd[((s_ * 3 + 2) * (MT * 64) + cell) * 8 + ci] = (unsigned short)(__float_as_uint(w3) >> 16);
+            }
+        }
+    };
+    for (int i = tid; i < 2 * WB; i += NT) Ws[i] = fdn_u32x4{0u, 0u, 0u, 0u};      // the tenth tap and channels past the tensor stay zero
+    __syncthreads();
     f32x16 acc[2][MT];
 #pragma unroll
     for (int st = 0; st < 2; ++st)
@@ -248,32 +281,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tiled_kernel(C3Args a, int til
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[st][m][r] = 0.f;
 
-    fetch(0);
-    stash(0);
+    fetch(0, stg[0]);
+    if (nchunk > 1) fetch(1, stg[1]);
+    stash(0, stg[0]);
     __syncthreads();
-    const int row0 = 2 * wave;                  // this wave's two output rows of the tile
-    for (int c = 0; c < nchunk; ++c) {
-        const bool more = c + 1 < nchunk;
-        if (more) fetch(c + 1);
-        const float* xb = Xl + (c & 1) * XB + kh * PL + row0 * HC + ln;
-        const float* wb = Wl + (c & 1) * WB + kh * WS + ln;
+    const int row0 = 2 * wave;
+    int toff[KS5];                              // this lane half's tap of every k-step, as an offset into the staged tile
 #pragma unroll
-        for (int s = 0; s < KST; ++s) {
-            const int tap = s / (CK / 2), cp = s - tap * (CK / 2), dy = tap / 3, dx = tap - dy * 3;      // compile-time after unrolling
-            const float b0 = xb[(2 * cp) * PL + dy * HC + dx];
-            const float b1 = xb[(2 * cp) * PL + (dy + 1) * HC + dx];
+    for (int s_ = 0; s_ < KS5; ++s_) {
+        const int tap = min(2 * s_ + kh, 8), dy = tap / 3, dx = tap - dy * 3;
+        toff[s_] = (row0 + dy) * HC + ln + dx;
+    }
+    auto chunk_step = [&](int c, Stage& mine, const Stage& nxt) __attribute__((always_inline)) {
+        // `mine` held chunk c (parked in LDS already): refill it with chunk c + 2; `nxt` holds chunk c + 1
+        const bool more = c + 1 < nchunk;
+        if (c + 2 < nchunk) fetch(c + 2, mine);
+        const fdn_u32x4* xb = Xs + (c & 1) * XB;
+        const fdn_u32x4* wb = Ws + (c & 1) * WB + lane;
+#pragma unroll
+        for (int s_ = 0; s_ < KS5; ++s_) {
+            const fdn_u32x4 b0[3] = {xb[toff[s_]], xb[NPOS + toff[s_]], xb[2 * NPOS + toff[s_]]};
+            const fdn_u32x4 b1[3] = {xb[toff[s_] + HC], xb[NPOS + toff[s_] + HC], xb[2 * NPOS + toff[s_] + HC]};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const float av = wb[(2 * s) * WS + m * 32];
-                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0][m], 0, 0, 0);
-                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1][m], 0, 0, 0);
+                const fdn_u32x4 av[3] = {wb[((s_ * 3 + 0) * MT + m) * 64], wb[((s_ * 3 + 1) * MT + m) * 64], wb[((s_ * 3 + 2) * MT + m) * 64]};
+                acc[0][m] = fdn_mfma_split6(av, b0, acc[0][m]);
+                acc[1][m] = fdn_mfma_split6(av, b1, acc[1][m]);
             }
         }
-        if (more) stash((c + 1) & 1);
+        if (more) stash((c + 1) & 1, nxt);
         __syncthreads();
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk_step(c, stg[0], stg[1]);
+        if (c + 1 < nchunk) chunk_step(c + 1, stg[1], stg[0]);
     }
-    // epilogue: rows y0 + row0 + {0, 1}, columns x0 + ln; the activation kind is resolved once, not per value
-    const unsigned nb4 = (unsigned)N * P4;
+    const unsigned nb4 = (unsigned)nvalid * P4;
     const long obase = ((long)b * a.CoutT + a.n0) * P;
     const rsrc_t ro = mk_rsrc(a.out + obase, nb4);
     const rsrc_t rr = mk_rsrc(a.res ? a.res + obase : a.out, a.res ? nb4 : 0u);
@@ -282,23 +325,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tiled_kernel(C3Args a, int til
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             const int gy = y0 + row0 + st, gx = x0 + ln;
-            const unsigned voff = (gy < H && gx < W) ? (4u * kh * P + (unsigned)(gy * W + gx)) * 4u : 0x80000000u;     // outside: dropped / 0
+            const unsigned voff = (gy < H && gx < W) ? (4u * kh * P + (unsigned)(gy * W + gx)) * 4u : 0x80000000u;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float rv[16];
                 if (a.res) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = bload(rr, voff, (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * P4);
+                    for (int r = 0; r < 16; ++r) {
+                        const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
+                        rv[r] = bload(rr, (nrow + 4 * kh < nvalid) ? voff : 0x80000000u, (unsigned)nrow * P4);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int nrow = m * 32 + (r & 3) + 8 * (r >> 2);
                     float v = acc[st][m][r];
-                    if (a.bias) v += a.bias[a.n0 + nrow + 4 * kh];
+                    if (a.bias) v += a.bias[a.n0 + min(nrow + 4 * kh, nvalid - 1)];
                     if (a.res && a.res_before_act) v += rv[r];
                     v = apply_act(v, act_);
                     if (a.res && !a.res_before_act) v += rv[r];
-                    bstore(v + a.post_add, ro, voff, (unsigned)nrow * P4);
+                    bstore(v + a.post_add, ro, (nrow + 4 * kh < nvalid) ? voff : 0x80000000u, (unsigned)nrow * P4);      // (a channel past the tensor: dropped)
                 }
             }
         }
@@ -306,16 +352,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tiled_kernel(C3Args a, int til
     if (a.act == FDN_ACT_NONE) epilogue(std::false_type{}); else epilogue(std::true_type{});
 }
 
-template <int MT>
-int launch_tiled(const C3Args& a, hipStream_t s) {
-    constexpr int N = MT * 32;
-    const size_t lds = (2UL * CK * PL + 2UL * 9 * CK * (N + 1)) * sizeof(float);
-    auto kern = conv3x3_tiled_kernel<MT>;
+template <int MT, int NW>
+int launch_split(const C3Args& a, hipStream_t s) {
+    constexpr int N = MT * 32, TH_ = 2 * NW;
+    const size_t lds = 2UL * (3UL * (TH_ + 2) * HC + 5UL * 3 * MT * 64) * sizeof(fdn_u32x4);
+    auto kern = conv3x3_split_kernel<MT, NW>;
     if (lds > 48 * 1024 && !fdn_allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return FDN_ERR_LAUNCH;
-    const int tx = cdiv(a.W, TW), ty = cdiv(a.H, TH);
-    const long total = (long)tx * ty * a.B * (a.Cout / N);      // one launch: the output-channel groups of 32 * MT are part of the grid
+    const int tx = cdiv(a.W, TW), ty = cdiv(a.H, TH_);
+    const long total = (long)tx * ty * a.B * cdiv(a.Cout, N);
     if (total > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), lds, s, a, tx, ty);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), lds, s, a, tx, ty);
     return fdn_launch_status();
 }
 
@@ -351,9 +397,8 @@ int fdn_conv3x3_mfma(const float* x, const float* w, const float* bias, const fl
     a.act = act; a.res_before_act = res_before_act; a.post_add = post_add;
     a.tiles_per_img = a.total_tiles = 0;
     a.n0 = 0; a.CoutT = Cout;
-    if (Cin % CK == 0 && Cin >= 2 * CK && (Cout == 32 || Cout % 64 == 0)) {
-        return Cout == 32 ? launch_tiled<1>(a, s) : launch_tiled<2>(a, s);     // wider outputs: groups of 64 channels (four accumulator tiles x two strips spill)
-    }
+    if (Cin % CK == 0 && Cin >= 2 * CK && Cout >= 16)           // LDS-tiled, both operands as three bf16 parts on the bf16 matrix pipe
+        return Cout <= 32 ? launch_split<1, 4>(a, s) : launch_split<2, 8>(a, s);      // (8 x 32 tiles, two workgroups per CU / 16 x 32, one)
     const int tiles = (Cout + 31) / 32;
     if (tiles == 1) return launch<1, 4>(a, s);
     if (tiles == 2) return launch<2, 4>(a, s);

@@ -358,11 +358,11 @@ extern "C" int fdn_conv2d(const float* x, const float* w, const float* bias, con
     a.act = act; a.res_before_act = res_before_act; a.post_add = post_add;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (KH == 3 && KW == 3 && pad == 1 && (stride == 1 || stride == 2)) {
-        // measured at B=8 720p (tools/gpu_conv_shapes.py): the LDS-weight direct kernel beats the MFMA implicit GEMM
-        // up to 64 output channels (64->32 @L1 5.5 vs 8.4 ms, 12->12 0.47 vs 2.0 ms); wider ones (64->128,
-        // 128->64, whose weight slice does not fit LDS either) stay on MFMA
+        // measured at B=8 720p (tools/ab_conv3x3.py, tools/gpu_conv_shapes.py): Cin % 8 == 0 with at least 16 output channels
+        // goes to the LDS-tiled split-bf16 MFMA form (64->32 @L1 2.3 ms against 5.5 ms direct, 24->24 0.21 against 0.89 ms);
+        // the LDS-weight direct kernel keeps the narrow ones (12->12 0.47 ms against 2.0 ms on the flat MFMA form)
         int rc = FDN_ERR_UNSUPPORTED;
-        if (stride == 1 && Cin % 8 == 0 && Cin >= 16 && (Cout == 32 || Cout % 64 == 0)) {          // LDS-tiled MFMA form
+        if (stride == 1 && Cin % 8 == 0 && Cin >= 16 && Cout >= 16) {          // LDS-tiled MFMA form (split-bf16 operands, conv3x3.hip)
             rc = fdn_conv3x3_mfma(x, w, bias, res, out, B, Cin, H, W, Cout, act, res_before_act, post_add, s);
             if (rc != FDN_ERR_UNSUPPORTED) return rc;
         }

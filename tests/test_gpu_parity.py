@@ -387,9 +387,14 @@ def test_conv3x3_paths(A, Cin, Cout, H, W, stride):
 
 
 @pytest.mark.parametrize("Cin,Cout,H,W,act,res_before", [(16, 32, 8, 32, 0, False), (64, 32, 37, 70, 2, True), (128, 64, 19, 33, 0, False),
-                                                          (24, 64, 5, 100, 2, False), (32, 64, 64, 64, 0, True), (64, 128, 9, 40, 1, True)])
+                                                          (24, 64, 5, 100, 2, False), (32, 64, 64, 64, 0, True), (64, 128, 9, 40, 1, True),
+                                                          (24, 24, 21, 45, 1, False), (48, 48, 17, 33, 2, True), (16, 17, 9, 31, 0, False),
+                                                          (32, 100, 20, 36, 1, True)])
 def test_conv3x3_tiled_options(A, Cin, Cout, H, W, act, res_before):
-    """LDS-tiled MFMA 3x3 (Cin % 8 == 0, Cout 32 / 64): partial tiles on both axes, bias, activation, residual before / after it."""
+    """LDS-tiled MFMA 3x3 (Cin % 8 == 0, Cout >= 16; three-way bf16 split of both operands on the bf16 matrix pipe, fp32-exact to
+    rounding): partial tiles on both axes, channel groups that end inside a 32-channel tile (24, 48, 17, 100: nothing may be
+    written past the tensor - the batch of 2 puts the next image's planes right behind), bias, activation, residual before /
+    after it."""
     from fdn_hip import ops
     x, w, b = _rnd(2, Cin, H, W, seed=1), _rnd(Cout, Cin, 3, 3, seed=2) / (3 * Cin ** 0.5), _rnd(Cout, seed=3)
     res = _rnd(2, Cout, H, W, seed=4)
@@ -404,6 +409,7 @@ def test_conv3x3_tiled_options(A, Cin, Cout, H, W, act, res_before):
         y = y + res.double()
     got = ops.conv2d(dev(x), dev(w), dev(b), pad=1, act=act, res=dev(res), res_before_act=res_before)
     assert rel_rms(got.cpu(), y) < 2e-6
+    assert rel_rms(got.cpu()[1, :1], y[1, :1]) < 2e-6           # (the plane right behind image 0's last channel)
     plain = ops.conv2d(dev(x), dev(w), None, pad=1)
     assert rel_rms(plain.cpu(), torch.nn.functional.conv2d(x.double(), w.double(), padding=1)) < 2e-6
 
