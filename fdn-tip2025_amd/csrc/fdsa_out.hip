@@ -302,9 +302,11 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             if (DB && g == 2) {
                 // the NEXT tile's v_value and group 0 go into the two register sets that are dead from here (v_value was last used
                 // just above, the idle set holds group 1): their round trip hides behind this tile's last MFMAs and its epilogue
+                // (fp32 storage only: a bf16 load is followed by its unpacking, which would wait for the data right here - measured
+                //  16.3 -> 30.9 ms per step at 1080p with the prefetch in the bf16 form)
                 const int nt = tile + (int)gridDim.x;
-                fetched = nt < a.total_tiles;
-                if constexpr (DB) if (fetched) {
+                fetched = !IBF && nt < a.total_tiles;
+                if constexpr (DB && !IBF) if (fetched) {
                     const int nb = tile_b(nt);
                     const unsigned np_ = tile_p(nt, nb);
                     const unsigned nvoff = (kh * P + (np_ < P ? np_ : P - 2)) * IES;

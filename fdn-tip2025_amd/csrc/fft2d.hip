@@ -260,8 +260,8 @@ __device__ void fft_pass_reg(const float2* src, float2* dst, int N, int Ns, int 
     }
 }
 
-// BIG: 0 = register butterflies for the radices 2-7 only, 1 = + 17 / 23 (1080p / 720p lengths), 2 = + 37 / 41 (the (H + 2)-row
-// maps of fourier_fuse: 738 = 41 * 18, 370 = 37 * 10) - tiers, because the widest butterfly sets the kernel's register count
+// BIG: 0 = register butterflies for the radices 2-7 only, 1 = + 17 / 23 (1080p / 720p lengths), 2 = + 13 / 37 / 41 (the (H + 2)-row
+// maps of fourier_fuse: 738 = 41 * 18, 370 = 37 * 10, 546 = 13 * 42) - tiers, because the widest butterfly sets the kernel's register count
 template <bool INV, int BIG>
 __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, int nseq, int ss, int es, bool seq_fast,
                          const float2* __restrict__ tw, int tab_mul) {
@@ -274,6 +274,7 @@ __device__ void fft_pass(const float2* src, float2* dst, int N, int Ns, int R, i
         case 3: fft_pass_reg<INV, 3>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
         case 5: fft_pass_reg<INV, 5>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
         case 7: fft_pass_reg<INV, 7>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return;
+        case 13: if (BIG == 2) { fft_pass_reg<INV, 13>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;   // 546 = 13 * 42 (1080p)
         case 17: if (BIG) { fft_pass_reg<INV, 17>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
         case 23: if (BIG) { fft_pass_reg<INV, 23>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
         case 37: if (BIG == 2) { fft_pass_reg<INV, 37>(src, dst, N, Ns, nseq, ss, es, seq_fast, tw, tab_mul); return; } break;
@@ -866,6 +867,8 @@ template <int R, int P> struct ColPlan {
 };
 
 template <int R, int P, int MODE>
+// (two workgroups per CU: the FCAFFN mode takes 256 registers because of its out-of-line full-range sincos path - the hot path has
+//  no scratch access; capped at 168 registers for three workgroups the hot path spills and runs 0.99 against 0.78 ms, tools/ab_cols_pitch.py)
 __global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
     constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = ColPlan<R, P>::KS, NJ = R * NG, NT = ColPlan<R, P>::NT;
     static_assert(TC / CJ == NG, "8 column groups");
@@ -1135,7 +1138,7 @@ bool plan_big(const Plan& p) {
 }
 bool plan_big2(const Plan& p) {
     for (int i = 0; i < p.nst; ++i)
-        if (p.radix[i] == 37 || p.radix[i] == 41) return true;
+        if (p.radix[i] == 13 || p.radix[i] == 37 || p.radix[i] == 41) return true;
     return false;
 }
 

@@ -2,6 +2,9 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+import fdn_hip
+if len(sys.argv) > 1 and sys.argv[1] != "default":          # another build of the library
+    fdn_hip._LIB_PATH = os.path.abspath(sys.argv[1])
 import torch
 from fdn_hip import ops
 dev = torch.device("cuda:0")
