@@ -390,11 +390,7 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int xx = tx0 - 1 + c0 + j;
-#ifdef FDN_KO_GELU
-                mid[r * LSM + c0 + j] = (yok && xx >= 0 && xx < W) ? o8[j] : 0.f;
-#else
                 mid[r * LSM + c0 + j] = (yok && xx >= 0 && xx < W) ? gelu_fast(o8[j]) : 0.f;     // (a select around an unconditional GELU measured slower: 2.18 vs 1.83 ms)
-#endif
             }
         };
         ring_segment(tid);                                        // 256 of the 272 segments
@@ -419,9 +415,7 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) a = fmaf(k0[dy * 3 + dx], tin[(r + dy) * LS2 + cc + dx], a);
-#ifndef FDN_KO_GELU
                 a = gelu_fast(a);
-#endif
             }
             mid[r * LSM + cc] = a;
         }
@@ -440,9 +434,6 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
         // ---- B: tin is free: park the prefetched halo; second conv; column transforms --------------
         if (more) stash();
         float sp[8];
-#if defined(FDN_KO_DW2)
-        for (int j = 0; j < 8; ++j) sp[j] = mid[(py * 8 + rr + 1) * LSM + px * 8 + j + 1];
-#else
         {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sp[j] = 0.f;
@@ -457,13 +448,8 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
                     for (int dx = 0; dx < 3; ++dx) sp[j] = fmaf(k2[dy * 3 + dx], v[j + dx], sp[j]);
             }
         }
-#endif
         // columns: forward, z * ffta * e^{-i fftp}, inverse  (FDN_arch.py:460-469)
-#ifdef FDN_KO_COL
-        if (tid < 0) {
-#else
         if (tid < NP * 5) {
-#endif
             const int pj = tid / 5, kx = tid - pj * 5;
             float2 z[8];
 #pragma unroll
@@ -488,9 +474,6 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
             irfft8_row(xk, r);
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] += sp[j];                                                              // :470
-#ifdef FDN_KO_STORE
-            if (r[0] == 123.456f)
-#endif
             st_store8<OBF>(r, rout, ooff, (unsigned)c * hwo);
         }
         __syncthreads();                                          // S, mid, filt are rewritten by the next channel
@@ -650,33 +633,21 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         const fdn_u32x4* wp_ = reinterpret_cast<const fdn_u32x4*>(a.wpk) + ((long)ch * KS) * 64 + lane;      // (!AW_AHEAD: operands straight from L1 / L2)
 #pragma unroll
         for (int si = 0; si < 3; ++si) {
-#ifdef FDN_KOF_MFMA
-            if (ch == 0 && wave + 4 * si < FNS) {
-#else
             if (wave + 4 * si < FNS) {                              // wave-uniform
-#endif
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-#ifdef FDN_KOF_NOMFMA
-                for (int ks = 0; ks < KST; ++ks)
-                    for (int r = 0; r < 16; ++r) acc[r] += __uint_as_float(aw[3 * ks][r & 3]) * __uint_as_float(xb[si][ks][r % 3][r >> 2]);
-#else
                 for (int ks = 0; ks < KST; ++ks) {
                     const fdn_u32x4 a3[3] = {AW_AHEAD ? aw[3 * ks] : wp_[(3 * ks) * 64], AW_AHEAD ? aw[3 * ks + 1] : wp_[(3 * ks + 1) * 64],
                                              AW_AHEAD ? aw[3 * ks + 2] : wp_[(3 * ks + 2) * 64]};
                     acc = fdn_mfma_split6(a3, xb[si][ks], acc);
                 }
-#endif
                 const bool one = (onebits >> si) & 1u;
                 const fdn_u32x4 xone = {one ? 0x3F803F80u : 0u, one ? 0x00003F80u : 0u, 0u, 0u};
                 acc = fdn_mfma_bf16(AW_AHEAD ? aw[KS - 1] : wp_[(KS - 1) * 64], xone, acc);          // + bias: b1 + b2 + b3 against 1, 1, 1 (0 outside the image)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-#ifdef FDN_KOF_NOHID
-                    if (acc[0] == 123.456f)
-#endif
                     hid[((r & 3) + 8 * (r >> 2) + 4 * kh) * FPL + pixoff[si]] = acc[r];   // row = kind * 8 + channel
             }
         }
@@ -703,12 +674,8 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
             for (int i = 0; i < 9; ++i) wkt[i] = wk9[i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o8[j] = 0.f;
-#ifdef FDN_KOF_STENCIL
-            for (int dy = 1; dy < 2; ++dy) {
-#else
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-#endif
                 float v[10];
 #pragma unroll
                 for (int j = 0; j < 10; ++j) v[j] = hp[dy * FRS + j];
@@ -730,11 +697,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         __syncthreads();
 
         // ---- columns: thread = (slot, kx): forward, recombine, inverse (as fdsa_core_kernel) ------------------------
-#ifdef FDN_KOF_COL
-        if (tid < 0) {
-#else
         if (tid < NP * 5) {
-#endif
             const int pj = tid / 5, kx = tid - pj * 5;
             float2 q[8], k[8], v[8];
 #pragma unroll
@@ -753,13 +716,8 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
             fft8<false>(v);
             if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             float2 o1[8], o2[8], o3[8];
-#ifdef FDN_KOF_RECOMB
-            for (int ky = 0; ky < 8; ++ky) { o1[ky] = q[ky]; o2[ky] = k[ky]; o3[ky] = make_float2(v[ky].x * fg[ky], v[ky].y); }
-            for (int ky = 8; ky < 8; ++ky) {
-#else
 #pragma unroll
             for (int ky = 0; ky < 8; ++ky) {
-#endif
                 const float f = fg[ky];
                 const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));            // :591-593
                 float2 qk = cmul(q[ky], k[ky]);                                               // :595
@@ -797,9 +755,6 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                 const int elv = 2 * i + kh, ev = e0 + elv;
                 float o8[8];
                 dw_row8(hid + (24 + elv) * FPL + row * FRS + px * 8, wks + (24 + elv) * 9, o8);
-#ifdef FDN_KOF_STORE
-                if (o8[0] == 123.456f)
-#endif
                 st_store8<OBF>(o8, rout, ev < E ? opix + (unsigned)(3 * E + ev) * hwo : OOB, 0);
             }
         }
@@ -813,9 +768,6 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
             for (int kx = 0; kx < 5; ++kx) xk[kx] = S[(t * NP + slot) * PS + kx * KXS + row];
             float r8[8];
             irfft8_row(xk, r8);
-#ifdef FDN_KOF_STORE
-            if (r8[0] == 123.456f)
-#endif
             st_store8<OBF>(r8, rout, e < E ? opix + (unsigned)(t * E + e) * hwo : OOB, 0);
         }
         if (more) stage_store();        // taps and gains of the next chunk (this chunk's were last read before the third barrier)
