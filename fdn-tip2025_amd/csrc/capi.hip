@@ -1,7 +1,7 @@
 // ABI bookkeeping for libfdn_hip.so.
 #include "common.hpp"
 
-extern "C" int fdn_abi_version(void) { return 8; }
+extern "C" int fdn_abi_version(void) { return 9; }
 
 extern "C" const char* fdn_error_string(int code) {
     switch (code) {

@@ -44,6 +44,10 @@ constexpr int TRI_E = 10;                     // LN3_GATE: channels e per chunk 
 struct SArgs {
     fdn_conv1x1_desc d;
     int tiles_per_img, total_ptiles, ntiles;
+    // FC form (fdn_fcaffn_in_packed): xb = x1 is normalised on load (stats [B][2][P], gamma / beta [K]; null: used as it is) and the
+    // epilogue's mul / add maps are evaluated from the 3-channel image (folded 3x3 o 1x1 weights as MFMA operands in `mapw`)
+    const float* xb_stats; const float* xb_gamma; const float* xb_beta;
+    const float* img; const fdn_u32x4* mapw; int img_w, img_h;
 };
 
 // k' (position in the packed K axis) -> source column of w / channel of x.  Natural order, or for LN3_GATE the triple order
@@ -55,10 +59,11 @@ __host__ __device__ __forceinline__ int tri_src(int kp, int E) {
     return e < E ? g * E + e : -1;
 }
 
-template <int PRO>
+template <int PRO, bool FC = false>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
     const fdn_conv1x1_desc& d = a.d;
     constexpr bool TRI = PRO == FDN_PRO_LN3_GATE, LN = PRO == FDN_PRO_LN, LNM = PRO == FDN_PRO_LN_MULADD;
+    static_assert(!FC || LNM, "the FCAFFN form is the LN_MULADD prologue plus its own epilogue");
     __shared__ fdn_u32x4 Xs[BLK];
     __shared__ fdn_u32x4 Ws[BLK];
     __shared__ float red[2][TP];
@@ -93,8 +98,16 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
             sb[g] = -sp[pix] * sa[g];
         }
     }
+    const bool x1ln = FC && a.xb_stats != nullptr;                            // uniform
+    float sa1 = 1.f, sb1 = 0.f;
+    if (x1ln) {
+        const float* sp = a.xb_stats + (long)b * 2 * P;
+        sa1 = sp[P + pix];
+        sb1 = -sp[pix] * sa1;
+    }
     float xv[16], vv[(TRI || LNM) ? (TRI ? 5 : 16) : 1];
     float ga[(TRI || LNM) ? 16 : 1], be[(TRI || LNM) ? 16 : 1];
+    float g1[FC ? 16 : 1], b1[FC ? 16 : 1];
     fdn_u32x4 wv[6];
     auto fetch = [&](int c) __attribute__((always_inline)) {
         if constexpr (TRI) {
@@ -118,6 +131,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
                     vv[i] = bload(rv, pix * 4u, (unsigned)(k0 + i) * P4);
                     ga[i] = k0 + i < K ? d.gamma[k0 + i] : 0.f;
                     be[i] = k0 + i < K ? d.beta[k0 + i] : 0.f;
+                    if constexpr (FC) {
+                        g1[i] = k0 + i < K ? (x1ln ? a.xb_gamma[k0 + i] : 1.f) : 0.f;
+                        b1[i] = (x1ln && k0 + i < K) ? a.xb_beta[k0 + i] : 0.f;
+                    }
                 }
             }
         }
@@ -138,7 +155,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if constexpr (LN) v[i] = k0 + i < K ? fmaf(xv[i], sa[0], sb[0]) : 0.f;       // affine part folded into the weights
-                else if constexpr (LNM) v[i] = fmaf(fmaf(fmaf(xv[i], sa[0], sb[0]), ga[i], be[i]), vv[i], vv[i]);     // norm(x) * x1 + x1, FDN_arch.py:420
+                else if constexpr (LNM) {
+                    float x1 = vv[i];
+                    if constexpr (FC) x1 = fmaf(fmaf(x1, sa1, sb1), g1[i], b1[i]);            // x1 = norm3(block input), FDN_arch.py:675
+                    v[i] = fmaf(fmaf(fmaf(xv[i], sa[0], sb[0]), ga[i], be[i]), x1, x1);       // norm(x) * x1 + x1, FDN_arch.py:420
+                }
                 else v[i] = xv[i];
             }
         }
@@ -212,6 +233,76 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
     const rsrc_t rr = mk_rsrc(RES ? d.res + (long)b * d.rbs + (long)n0 * P : MA ? d.mul + (long)b * d.mbs + (long)n0 * P : d.out, (RES || MA) ? (unsigned)Nt * P4 : 0u);
     const rsrc_t ra = mk_rsrc(MA ? d.add + (long)b * d.mbs + (long)n0 * P : d.out, MA ? (unsigned)Nt * P4 : 0u);
     const rsrc_t rbias = mk_rsrc(d.bias ? d.bias + n0 : d.w, d.bias ? (unsigned)Nt * 4u : 0u);     // no bias: empty descriptor, reads 0
+    if constexpr (FC) {
+        // x * conv3_mul(conv1_mul(img)) + conv3_add(conv1_add(img))  (FDN_arch.py:423): the two maps of this wave's 64 pixels x 64
+        // channels as MFMA chains over the 27 (tap, image channel) products, k = 3 tap + channel, zero outside the image
+        const int Wd = a.img_w, Hh = a.img_h;
+        const rsrc_t ri = mk_rsrc(a.img + (long)b * 3 * P, 3u * P4);
+        fdn_u32x4 Bm[2][2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned pc = min(p0 + (unsigned)(wi * 64 + s * 32 + ln), P - 1);
+            const int y = (int)(pc / (unsigned)Wd), x = (int)pc - y * Wd;
+            const bool up = y > 0, dn = y < Hh - 1, lf = x > 0, rt = x < Wd - 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk0 = 16 * ks + j, kk1 = kk0 + 8;                       // lane half 0 / 1
+                    const int t0 = kk0 / 3, c0 = kk0 - 3 * t0, dy0 = t0 / 3 - 1, dx0 = t0 % 3 - 1;
+                    const int t1 = kk1 / 3, c1 = kk1 - 3 * t1, dy1 = t1 / 3 - 1, dx1 = t1 % 3 - 1;
+                    const bool in0 = kk0 < 27 && (dy0 < 0 ? up : dy0 > 0 ? dn : true) && (dx0 < 0 ? lf : dx0 > 0 ? rt : true);
+                    const bool in1 = kk1 < 27 && (dy1 < 0 ? up : dy1 > 0 ? dn : true) && (dx1 < 0 ? lf : dx1 > 0 ? rt : true);
+                    const int off0 = c0 * (int)P + dy0 * Wd + dx0, off1 = c1 * (int)P + dy1 * Wd + dx1;
+                    const bool in = kh ? in1 : in0;
+                    const int off = kh ? off1 : off0;
+                    v[j] = bload(ri, in ? (unsigned)((int)pc + off) * 4u : 0x80000000u, 0u);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned u1, u2, u3;
+                    fdn_split3(v[2 * j], v[2 * j + 1], u1, u2, u3);
+                    Bm[s][ks][0][j] = u1; Bm[s][ks][1][j] = u2; Bm[s][ks][2][j] = u3;
+                }
+            }
+        }
+        const int nt32 = (N + 31) / 32;
+        const rsrc_t rb = mk_rsrc(d.bias ? d.bias + n0 : d.w, d.bias ? (unsigned)min(N - n0, TN) * 4u : 0u);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            f32x16 mac[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mac[s][t][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int ct = min(n0 / 32 + wj * 2 + t, nt32 - 1);                // (a tile past N: its rows are never stored)
+                    const fdn_u32x4* mp = a.mapw + ((long)((m * 2 + ks) * 3) * nt32 + ct) * 64 + lane;
+                    const fdn_u32x4 A3[3] = {mp[0], mp[(long)nt32 * 64], mp[(long)2 * nt32 * 64]};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) mac[s][t] = fdn_mfma_split6(A3, Bm[s][ks], mac[s][t]);
+                }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (m == 0) {
+                            const float bi = bload(rb, (unsigned)(4 * kh) * 4u, (unsigned)((wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
+                            acc[s][t][r] = (acc[s][t][r] + bi) * mac[s][t][r];
+                        } else {
+                            acc[s][t][r] += mac[s][t][r];
+                        }
+                    }
+        }
+    }
     float psum[2] = {0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -221,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
         for (int t = 0; t < 2; ++t) {
             float rv_[16], av_[16], bi_[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bi_[r] = bload(rbias, (unsigned)(4 * kh) * 4u, (unsigned)((wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
+            for (int r = 0; r < 16; ++r) bi_[r] = FC ? 0.f : bload(rbias, (unsigned)(4 * kh) * 4u, (unsigned)((wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
             if (RES || MA) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv_[r] = bload(rr, voff, (unsigned)((wj * 2 + t) * 32 + (r & 3) + 8 * (r >> 2)) * P4);
@@ -288,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
 
 template <int PRO>
 int launch_split(const fdn_conv1x1_desc& d, hipStream_t s) {
-    SArgs a;
+    SArgs a = {};
     a.d = d;
     a.tiles_per_img = cdiv(d.P, TP);
     a.total_ptiles = d.B * a.tiles_per_img;
@@ -408,13 +499,41 @@ __global__ __launch_bounds__(256, 2) void gemm_split_strip_kernel(SArgs a) {
 
 template <int NKS, int PRO>
 int launch_strip(const fdn_conv1x1_desc& d, hipStream_t s) {
-    SArgs a;
+    SArgs a = {};
     a.d = d;
     a.tiles_per_img = cdiv(d.P, TP);
     a.total_ptiles = d.B * a.tiles_per_img;
     a.ntiles = 1;
     hipLaunchKernelGGL((gemm_split_strip_kernel<NKS, PRO>), dim3((unsigned)a.total_ptiles), dim3(256), 0, s, a);
     return fdn_launch_status();
+}
+
+// fdn_fcaffn_in_pack: the two folded image maps as MFMA A operands: cell (map, k-step, part, 32-channel tile, lane) holds the part-th
+// bf16 part of w3[c][tap] * w1[c][ch] (one fp32 rounding, as fdn_fcaffn_in folds them) for k = 16 ks + 8 kh + j = 3 tap + ch < 27
+__global__ void pack_imgmod_kernel(const float* __restrict__ w1m, const float* __restrict__ w3m, const float* __restrict__ w1a,
+                                   const float* __restrict__ w3a, fdn_u32x4* __restrict__ out, int C, int nt32, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), ct = (int)((i >> 6) % nt32);
+    const long q = (i >> 6) / nt32;
+    const int part = (int)(q % 3), ks = (int)((q / 3) % 2), m = (int)(q / 6);
+    const int c = ct * 32 + (lane & 31), kh = lane >> 5;
+    const float* w1 = m ? w1a : w1m;
+    const float* w3 = m ? w3a : w3m;
+    fdn_u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kk = 16 * ks + 8 * kh + 2 * j + u;
+            float x = (c < C && kk < 27) ? w3[(long)c * 9 + kk / 3] * w1[(long)c * 3 + kk % 3] : 0.f;
+            for (int p = 0; p < part; ++p) x -= __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+            v[u] = x;
+        }
+        o[j] = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
+    }
+    out[i] = o;
 }
 
 // one thread per 16-byte unit of the packed weights: 8 consecutive k' of one output row, one of the three bf16 parts
@@ -463,6 +582,52 @@ int fdn_gemm_split(const fdn_conv1x1_desc& d, hipStream_t s) {
         case FDN_PRO_LN_MULADD: return launch_split<FDN_PRO_LN_MULADD>(d, s);
     }
     return FDN_ERR_UNSUPPORTED;
+}
+
+extern "C" long fdn_conv1x1_pack_bytes(int N, int K, int ln3_E);
+extern "C" long fdn_fcaffn_in_pack_bytes(int C) {
+    return fdn_conv1x1_pack_bytes(C, C, 0) + 2L * 2 * 3 * cdiv(C, 32) * 64 * 16;
+}
+
+extern "C" int fdn_fcaffn_in_pack(const float* w, const float* w1_mul, const float* w3_mul, const float* w1_add, const float* w3_add, int C,
+                                  void* wpk, fdn_stream_t stream) {
+    FDN_CHECK_ARG(w && w1_mul && w3_mul && w1_add && w3_add && wpk && C > 0);
+    if (int e = fdn_conv1x1_pack(w, C, C, 0, wpk, stream)) return e;
+    const int nt32 = cdiv(C, 32);
+    const long total = 2L * 2 * 3 * nt32 * 64;
+    fdn_u32x4* maps = reinterpret_cast<fdn_u32x4*>(static_cast<char*>(wpk) + fdn_conv1x1_pack_bytes(C, C, 0));
+    hipLaunchKernelGGL(pack_imgmod_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w1_mul, w3_mul,
+                       w1_add, w3_add, maps, C, nt32, total);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_fcaffn_in_packed(const float* xi, const float* stats_xi, const float* x1, const float* stats1, const float* gamma1,
+                                    const float* beta1, const float* img, const void* wpk, const float* gamma, const float* beta, float* out,
+                                    int B, int C, int H, int W, fdn_stream_t stream) {
+    FDN_CHECK_ARG(xi && stats_xi && x1 && img && wpk && gamma && beta && out && B > 0 && C > 0 && H > 0 && W > 0);
+    FDN_CHECK_ARG((stats1 && gamma1 && beta1) || (!stats1 && !gamma1 && !beta1));
+    const long P = (long)H * W;
+    if (C < 96 || (unsigned long long)(C + 4) * 4ull * P > 0x7FFFFFFFull) return FDN_ERR_UNSUPPORTED;      // narrower: fdn_fcaffn_in
+    if ((long)B * cdiv(P, TP) * cdiv(C, TN) > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
+    SArgs a = {};
+    fdn_conv1x1_desc& d = a.d;
+    d.x[0] = xi; d.xbs[0] = (long)C * P; d.kseg[0] = C;
+    d.w = static_cast<const float*>(wpk);          // (not read: the packed form below carries the weights)
+    d.wpk = wpk;
+    d.out = out; d.obs = (long)C * P;
+    d.B = B; d.K = C; d.N = C; d.P = (int)P;
+    d.pro = FDN_PRO_LN_MULADD; d.stats = stats_xi; d.gamma = gamma; d.beta = beta;
+    d.xb = x1; d.xbbs = (long)C * P;
+    d.act = FDN_ACT_NONE; d.epi = FDN_EPI_NONE;
+    a.xb_stats = stats1; a.xb_gamma = gamma1; a.xb_beta = beta1;
+    a.img = img; a.img_w = W; a.img_h = H;
+    a.mapw = reinterpret_cast<const fdn_u32x4*>(static_cast<const char*>(wpk) + fdn_conv1x1_pack_bytes(C, C, 0));
+    a.tiles_per_img = cdiv((int)P, TP);
+    a.total_ptiles = B * a.tiles_per_img;
+    a.ntiles = cdiv(C, TN);
+    hipLaunchKernelGGL((gemm_split_kernel<FDN_PRO_LN_MULADD, true>), dim3((unsigned)(a.total_ptiles * a.ntiles)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return fdn_launch_status();
 }
 
 extern "C" long fdn_conv1x1_pack_bytes(int N, int K, int ln3_E) {

@@ -351,6 +351,29 @@ def fcaffn_in(xi, x1, img, w, gamma, beta, w1_mul, w3_mul, w1_add, w3_add, x1_ln
     return out
 
 
+FCAFFN_PACKED_MIN_C = 96          # widths from which the split-bf16 GEMM form (fdn_fcaffn_in_packed) takes the sub-block
+
+
+def fcaffn_in_pack(w, w1_mul, w3_mul, w1_add, w3_add):
+    """project_in [C, C] and the two folded image maps as split-bf16 MFMA operands (fdn_fcaffn_in_pack), once per weight set."""
+    C = w.shape[0]
+    wpk = torch.empty(lib().fdn_fcaffn_in_pack_bytes(C), device=w.device, dtype=torch.uint8)
+    check(lib().fdn_fcaffn_in_pack(_flat(w.reshape(C, C), "w"), _flat(w1_mul, "w1_mul"), _flat(w3_mul, "w3_mul"), _flat(w1_add, "w1_add"),
+                                   _flat(w3_add, "w3_add"), C, ctypes.c_void_p(wpk.data_ptr()), stream()), "fdn_fcaffn_in_pack")
+    return wpk
+
+
+def fcaffn_in_packed(xi, stats_xi, x1, img, wpk, gamma, beta, x1_ln=None):
+    """fcaffn_in for C >= FCAFFN_PACKED_MIN_C (level 3): one launch on the split-bf16 GEMM; stats_xi = chan_stats(xi)."""
+    B, C, H, W = xi.shape
+    out = torch.empty_like(xi)
+    st1, g1, b1 = x1_ln if x1_ln is not None else (None, None, None)
+    check(lib().fdn_fcaffn_in_packed(_flat(xi, "xi"), _flat(stats_xi, "stats_xi"), _flat(x1, "x1"), _flat(st1, "stats1"), _flat(g1, "gamma1"),
+                                     _flat(b1, "beta1"), _flat(img, "img"), ctypes.c_void_p(wpk.data_ptr()), _flat(gamma, "gamma"),
+                                     _flat(beta, "beta"), _flat(out, "out"), B, C, H, W, stream()), "fdn_fcaffn_in_packed")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # full-image FFT pipeline
 # ---------------------------------------------------------------------------------------------

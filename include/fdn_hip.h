@@ -170,6 +170,21 @@ int fdn_fcaffn_in(const float* xi, const float* x1, const float* stats1, const f
                   const float* w, const float* gamma, const float* beta, const float* w1_mul, const float* w3_mul,
                   const float* w1_add, const float* w3_add, float* out, int B, int C, int H, int W, fdn_stream_t stream);
 
+/* The same sub-block for wide layers (C >= 96: level 3, where the register strip of fdn_fcaffn_in does not fit), on the split-bf16
+ * GEMM of fdn_conv1x1 (128 pixels x 128 channels per workgroup): x1's LayerNorm on load, `norm(xi) * x1 + x1` as the GEMM prologue,
+ * and in the epilogue the two image maps as MFMA chains over the 27 (tap, image channel) products of the folded weights
+ * w3[c][tap] * w1[c][ch] - replaces fdn_layernorm_chan(x1) + fdn_img_mod_maps(img) + fdn_conv1x1(FDN_PRO_LN_MULADD, FDN_EPI_MULADD)
+ * (FDN_arch.py:419-423, :675), whose 3 C planes of intermediates are never written.
+ * fdn_fcaffn_in_pack: w [C][C], w1_* [C][3], w3_* [C][9] -> wpk (fdn_fcaffn_in_pack_bytes(C) bytes), once per weight set.
+ * fdn_fcaffn_in_packed: stats_xi [B][2][H*W] from fdn_chan_stats(xi); stats1 / gamma1 / beta1 as in fdn_fcaffn_in (all three or
+ *   none).  C < 96 returns FDN_ERR_UNSUPPORTED (use fdn_fcaffn_in). */
+long fdn_fcaffn_in_pack_bytes(int C);
+int fdn_fcaffn_in_pack(const float* w, const float* w1_mul, const float* w3_mul, const float* w1_add, const float* w3_add, int C,
+                       void* wpk, fdn_stream_t stream);
+int fdn_fcaffn_in_packed(const float* xi, const float* stats_xi, const float* x1, const float* stats1, const float* gamma1,
+                         const float* beta1, const float* img, const void* wpk, const float* gamma, const float* beta, float* out,
+                         int B, int C, int H, int W, fdn_stream_t stream);
+
 /* FCAFFN spatial modulation maps (FDN_arch.py:423): mul = conv3_mul(conv1_mul(img)),
  * add = conv3_add(conv1_add(img)).  img [B][3][H][W]; w1_* [C][3]; w3_* [C][9]; outs [B][C][H][W]. */
 int fdn_img_mod_maps(const float* img, const float* w1_mul, const float* w3_mul, const float* w1_add,

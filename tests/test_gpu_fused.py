@@ -147,6 +147,46 @@ def test_fcaffn_in_equals_unfused(A, C, H, W, B):
     assert rel_rms(got.cpu(), t * m64 + a64) < 2e-6
 
 
+@pytest.mark.parametrize("C,H,W,B", [(128, 16, 40, 2), (96, 9, 50, 1), (160, 8, 24, 2), (128, 5, 130, 1), (128, 184, 320, 1)])
+def test_fcaffn_in_packed_equals_unfused(A, C, H, W, B):
+    """fdn_fcaffn_in_packed (C >= 96: the level-3 sub-block on the split-bf16 GEMM - x1's LayerNorm on load, the LN * x1 + x1 prologue, the
+    image maps as MFMA chains in the epilogue) against the unfused route and against float64 math (FDN_arch.py:419-423, :675).
+    Shapes: rows shorter / longer than a 128-pixel tile (tiles crossing row ends and image borders), a 96-wide layer (FDN_lolv1),
+    160 channels (a second, partial channel tile), the bench shape."""
+    from fdn_hip import ops
+    xi, x1 = dev(_rnd(B, C, H, W, seed=1) * 1.3 + 0.2), dev(_rnd(B, C, H, W, seed=2))
+    img = dev(torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3)))
+    w = dev(_rnd(C, C, seed=4) / C ** 0.5)
+    g, b_ = dev(_rnd(C, seed=5) * 0.2 + 1.0), dev(_rnd(C, seed=6) * 0.1)
+    w1m, w3m = dev(_rnd(C, 3, seed=7)), dev(_rnd(C, 9, seed=8) / 3)
+    w1a, w3a = dev(_rnd(C, 3, seed=9)), dev(_rnd(C, 9, seed=10) / 3)
+    wpk = ops.fcaffn_in_pack(w, w1m, w3m, w1a, w3a)
+    st = ops.chan_stats(xi)
+    mul, add = ops.img_mod_maps(img, w1m, w3m, w1a, w3a)
+    ref = ops.conv1x1(xi, w, ln_muladd=(st, g, b_, x1), muladd=(mul, add))
+    got = ops.fcaffn_in_packed(xi, st, x1, img, wpk, g, b_)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 4e-6
+    assert rel_rms(got.cpu(), ref.cpu()) < 5e-7
+    g1, b1 = dev(_rnd(C, seed=11) * 0.2 + 1.0), dev(_rnd(C, seed=12) * 0.1)
+    raw = dev(_rnd(B, C, H, W, seed=13) * 2.0 + 0.5)
+    via_ln = ops.fcaffn_in_packed(xi, st, raw, img, wpk, g, b_, x1_ln=(ops.chan_stats(raw), g1, b1))
+    via_copy = ops.fcaffn_in_packed(xi, st, ops.layernorm_chan(raw, g1, b1), img, wpk, g, b_)
+    assert (via_ln - via_copy).abs().max().item() / via_copy.abs().max().item() < 4e-6
+    xd, x1d = xi.double().cpu(), x1.double().cpu()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, keepdim=True, unbiased=False)
+    u = ((xd - mu) / torch.sqrt(var + 1e-5) * g.double().cpu().view(1, -1, 1, 1) + b_.double().cpu().view(1, -1, 1, 1)) * x1d + x1d
+    t = torch.einsum("nk,bkhw->bnhw", w.double().cpu(), u)
+    F = torch.nn.functional
+    m64 = F.conv2d(F.conv2d(img.double().cpu(), w1m.double().cpu().view(C, 3, 1, 1)), w3m.double().cpu().view(C, 1, 3, 3), padding=1, groups=C)
+    a64 = F.conv2d(F.conv2d(img.double().cpu(), w1a.double().cpu().view(C, 3, 1, 1)), w3a.double().cpu().view(C, 1, 3, 3), padding=1, groups=C)
+    assert rel_rms(got.cpu(), t * m64 + a64) < 2e-6
+    import fdn_hip
+    with pytest.raises(fdn_hip.FdnHipError):                     # narrow layers belong to fdn_fcaffn_in
+        ops.fcaffn_in_packed(xi[:, :64].contiguous(), st, x1[:, :64].contiguous(), img, wpk, g[:64].contiguous(), b_[:64].contiguous())
+
+
 def test_fcaffn_in_beyond_4m_pixels(A):
     """More than 2^22 pixels per image: the pixel -> (row, column) split of the image-patch borders leaves the exact
     float-reciprocal range and takes the integer division."""
