@@ -133,6 +133,10 @@ def describe_call(name, a):
         B, C, H, W = (_iv(v) for v in a[14:18])
         f, b = 2.0 * B * H * W * C * (C + 2 * 27), 4.0 * B * H * W * (3 * C + 3)
         key = f"fdn_fcaffn_in[C={C},{H}x{W}]"
+    elif name == "fdn_fcaffn_in_packed":
+        B, C, H, W = (_iv(v) for v in a[11:15])
+        f, b = 2.0 * B * H * W * C * (C + 2 * 27), 4.0 * B * H * W * (3 * C + 3 + 4)        # xi, x1, out, the image, two statistics pairs
+        key = f"fdn_fcaffn_in_packed[C={C},{H}x{W}]"
     elif name == "fdn_conv2d":
         B, Cin, H, W, Cout, KH, KW, st, pad = (_iv(v) for v in a[5:14])
         OH, OW = (H + 2 * pad - KH) // st + 1, (W + 2 * pad - KW) // st + 1
