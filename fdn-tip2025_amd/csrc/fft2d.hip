@@ -919,8 +919,8 @@ __global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(Col
     bool liveq[CJ];
 #pragma unroll
     for (int cc = 0; cc < CJ; ++cc) {
-        liveq[cc] = col0 + cg * CJ + cc < Wf;
-        binq[cc] = (unsigned)(k1 * Wf + (liveq[cc] ? col0 + cg * CJ + cc : Wf - 1));
+        liveq[cc] = col0 + cc * NG + cg < Wf;                      // column cc of group cg = cc * 8 + cg: lanes of neighbouring groups hold
+        binq[cc] = (unsigned)(k1 * Wf + (liveq[cc] ? col0 + cc * NG + cg : Wf - 1));      // neighbouring columns (their 32-byte guidance records share lines)
     }
     const unsigned kstep = (unsigned)(R * Wf);      // bins between k2 and k2 + 1
     constexpr int NB = 4, BS = 32 / NB;             // guidance records in batches of 8, one batch in flight ahead of the arithmetic
@@ -947,7 +947,7 @@ __global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(Col
 
     if (worker) {
         f2 v[32];                                   // slot q = cc * P + (n2 | bit-reversed k2)
-        f2* yb = Y + k1 * KS + cg * CJ;
+        f2* yb = Y + k1 * KS + cg;
         // steps 3 and 4 for the FCAFFN mode.  FULL = false evaluates the 32 sincos with the fp32 range reduction only
         // (branch-free: 135 registers; with a range check at every site the allocator spills) and reports whether any
         // phase was outside its range; that case is redone from the LDS copy with the full-range form.
@@ -955,7 +955,7 @@ __global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(Col
             sfor<0, P>([&](auto n) {
                 constexpr int N2 = decltype(n)::value;
 #pragma unroll
-                for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = yb[N2 * TC + cc];
+                for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = yb[N2 * TC + cc * NG];
                 if constexpr (N2 > 0) {
                     const f2 w = twl[(N2 - 1) * R + k1];
 #pragma unroll
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(Col
                 for (int cc = 0; cc < CJ; ++cc) v[cc * P + N2] = fftr::cmulc(v[cc * P + N2], w);
             }
 #pragma unroll
-            for (int cc = 0; cc < CJ; ++cc) yb[N2 * TC + cc] = v[cc * P + N2];
+            for (int cc = 0; cc < CJ; ++cc) yb[N2 * TC + cc * NG] = v[cc * P + N2];
         });
     } else if (MODE == COL_FWD) {
         return;
