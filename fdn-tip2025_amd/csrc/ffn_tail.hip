@@ -228,7 +228,7 @@ constexpr int SW_LS = 68;                 // LDS row stride of a halo plane (66 
 constexpr unsigned SW_OOB = 0x80000000u;
 
 template <int MT, int R, bool IBF>
-__global__ __launch_bounds__(256, (R * MT <= 4) ? 2 : 1) void ffn_tail_sw_kernel(FtArgs a) {
+__global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel(FtArgs a) {
     constexpr int HRW = 2 * R + 2;                       // halo rows of the tile
     constexpr int PLN = HRW * SW_LS + 4;                 // floats per plane (+ spare cells)
     constexpr int NV4 = HRW * 16;                        // float4 of the 64 interior columns
@@ -480,7 +480,9 @@ extern "C" int fdn_ffn_tail(const void* y_, const float* dw_w, const float* w, c
     if (form == 1) {                                             // sliding-window form: N <= 64, 16-byte input lanes
         if (W % 4 != 0 || (reinterpret_cast<uintptr_t>(y) & 15) != 0 || mt > 2) return FDN_ERR_UNSUPPORTED;
         if (mt == 1) return y_bf16 ? launch_sw<1, 4, true>(a, s) : launch_sw<1, 4, false>(a, s);
-        return y_bf16 ? launch_sw<2, 2, true>(a, s) : launch_sw<2, 2, false>(a, s);
+        // (64-wide outputs: 8 x 64 tiles as well - half the barriers per pixel and 10 / 8 instead of 6 / 4 halo rows beat the third
+        //  workgroup per CU of the 4 x 64 tile: 0.636 -> 0.586 ms for the level-2 FCAFFN tail)
+        return y_bf16 ? launch_sw<2, 4, true>(a, s) : launch_sw<2, 4, false>(a, s);
     }
     if (y_bf16) return FDN_ERR_UNSUPPORTED;
     if (mt == 1) return launch<1>(a, s);
