@@ -565,11 +565,20 @@ __global__ void pack_split_kernel(const float* __restrict__ w, fdn_u32x4* __rest
 
 // FDN_ERR_UNSUPPORTED = not a shape of this kernel (fdn_conv1x1 then picks another)
 int fdn_gemm_split(const fdn_conv1x1_desc& d, hipStream_t s) {
-    if (!d.wpk || d.K < 96 || d.N < 96 || d.kseg[1] > 0 || d.kseg[2] > 0 || d.act != FDN_ACT_NONE || d.x_bf16 || d.out_bf16) return FDN_ERR_UNSUPPORTED;
-    if (d.stats_out && d.N > TN) return FDN_ERR_UNSUPPORTED;
+    if (!d.wpk || d.kseg[1] > 0 || d.kseg[2] > 0 || d.act != FDN_ACT_NONE || d.x_bf16 || d.out_bf16) return FDN_ERR_UNSUPPORTED;
     if ((long)d.B * cdiv(d.P, TP) * cdiv(d.N, TN) > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
     // short K, wide N, no epilogue: the activation strip stays in registers and the weights stream
-    if (d.K <= 128 && d.N >= 256 && d.N <= STRIP_MAX_N && d.epi == FDN_EPI_NONE && !d.stats_out && (d.pro == FDN_PRO_NONE || d.pro == FDN_PRO_LN)) {
+    const bool strip = d.N <= STRIP_MAX_N && d.epi == FDN_EPI_NONE && !d.stats_out && (d.pro == FDN_PRO_NONE || d.pro == FDN_PRO_LN);
+    // (round 3) the project_in convs of levels 1-2 as well (32 -> 86, 64 -> 172; FDN_lolv1 24 -> 64, 48 -> 129): on the fp32 MFMA they kept
+    // the vector ALU's datapath 60-90 % busy (64 -> 172: 0.49 -> 0.41 ms, 32 -> 86: 0.82 -> 0.75 ms here)
+    if (strip && d.K > 16 && d.K <= 64 && 2 * d.N >= 5 * d.K) {
+        const bool ln = d.pro == FDN_PRO_LN;
+        if (d.K > 48) return ln ? launch_strip<4, FDN_PRO_LN>(d, s) : launch_strip<4, FDN_PRO_NONE>(d, s);
+        if (d.K > 32) return ln ? launch_strip<3, FDN_PRO_LN>(d, s) : launch_strip<3, FDN_PRO_NONE>(d, s);
+        return ln ? launch_strip<2, FDN_PRO_LN>(d, s) : launch_strip<2, FDN_PRO_NONE>(d, s);
+    }
+    if (d.K < 96 || d.N < 96 || (d.stats_out && d.N > TN)) return FDN_ERR_UNSUPPORTED;
+    if (d.K <= 128 && d.N >= 256 && strip) {
         const bool ln = d.pro == FDN_PRO_LN;
         if (d.K > 112) return ln ? launch_strip<8, FDN_PRO_LN>(d, s) : launch_strip<8, FDN_PRO_NONE>(d, s);
         if (d.K > 96) return ln ? launch_strip<7, FDN_PRO_LN>(d, s) : launch_strip<7, FDN_PRO_NONE>(d, s);
