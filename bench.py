@@ -223,6 +223,18 @@ def kernel_roofline(key, rec, traffic):
     return out
 
 
+def matching_profile(shape, dtype):
+    """The newest committed profiles/*traffic_groups.json whose [batch, height, width] and storage dtype are the benchmarked ones
+    (tools/profile_merge.py output), or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_groups.json")), reverse=True):
+        d = json.load(open(f))
+        if list(d.get("shape", [])) == list(shape) and d.get("dtype", "f32") == dtype:
+            d["file"] = os.path.relpath(f, ROOT)
+            return d
+    return None
+
+
 def pmc_traffic_by_group(shape, dtype):
     """HBM bytes per launch of each kernel group from the committed rocprofv3 PMC passes: the newest
     profiles/*traffic_groups.json (written by tools/profile_merge.py: the memory-side request counters by size, FETCH_SIZE and
@@ -238,9 +250,10 @@ def pmc_traffic_by_group(shape, dtype):
 
 def rank_cpus(local_rank, world):
     """Host cores for this rank (one process per GPU; ~2,400 launches per step are issued from Python, so eight ranks must not pile
-    onto the same cores or sit across the socket from their GPU).  GPU r's NUMA-local cores from sysfs (amdgpu PCI functions in
-    bus order, `local_cpulist`), cut evenly between the ranks that share them; an even cut of the allowed cores when sysfs has
-    nothing to say.  Read-only, before any GPU call, no exec."""
+    onto the same cores or sit across the socket from their GPU).  GPU r's NUMA-local cores from sysfs (`local_cpulist` of the
+    PCI function that HIP device r is - every PCI domain, device order taken from the KFD topology and the *_VISIBLE_DEVICES
+    index lists), cut evenly between the ranks that share them; an even cut of the allowed cores when the order of the devices
+    cannot be established or sysfs has nothing to say.  Read-only, before any GPU call, no exec."""
     import glob
     allowed = sorted(os.sched_getaffinity(0))
 
@@ -252,12 +265,37 @@ def rank_cpus(local_rank, world):
                 out.update(range(int(lo), int(hi or lo) + 1))
         return out
 
+    def gpu_pci_ids():
+        """PCI ids (dddd:bb:dd.f) of the GPUs in HIP device order, without touching the GPU runtime: the KFD topology lists the
+        agents in the order ROCr enumerates them (nodes with SIMDs are GPUs; `domain` + `location_id` = PCI address), and
+        ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES (index lists) select from it.  None when the order cannot be established."""
+        nodes = []
+        for nd in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda q: int(os.path.basename(q))):
+            try:
+                props = dict(ln.split()[:2] for ln in open(os.path.join(nd, "properties")) if len(ln.split()) >= 2)
+            except OSError:
+                return None
+            if int(props.get("simd_count", "0")) > 0:
+                loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+                nodes.append("%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v:
+                try:
+                    nodes = [nodes[int(i)] for i in v.split(",")]
+                except (ValueError, IndexError):
+                    return None                 # UUID lists or stale indices: the order is unknown
+        return nodes or None
+
     local = []
-    for dev_dir in sorted(glob.glob("/sys/bus/pci/drivers/amdgpu/0000:*")):
-        try:
-            local.append(frozenset(cpulist(open(os.path.join(dev_dir, "local_cpulist")).read()) & set(allowed)))
-        except OSError:
-            pass
+    ids = gpu_pci_ids()
+    if ids is not None:
+        for pid in ids:
+            try:
+                local.append(frozenset(cpulist(open(f"/sys/bus/pci/devices/{pid}/local_cpulist").read()) & set(allowed)))
+            except OSError:
+                local = []
+                break
     if len(local) >= world and local[local_rank]:
         mine = local[local_rank]
         sharers = [r for r in range(world) if local[r] == mine]
@@ -287,27 +325,43 @@ def usable_cores():
 
 
 def cpu_baseline(h=256, w=256):
-    """The CPU oracle (fp32, PyTorch CPU ops = a port of the reference's algorithm) on ONE h x w image: BASELINE.json
-    configs[0] as it stands (`value_config0`), and scaled by pixel count to the 736x1280 unit of the metric (`value`).
-    The scaling flatters the CPU: the reference itself measured 0.0028 images/s at 736x1280 on 8 threads
-    because its working set leaves the caches - a bounded sample cannot show that."""
+    """The CPU oracle (fp32, PyTorch CPU ops = a port of the reference's algorithm) on ONE h x w image - BASELINE.json
+    configs[0] as it stands - timed the way SURVEY.md 8(d) asks: one warm-up, then the median of three runs, at n = 8 threads
+    (comparable with the build container's probe numbers) and at n = all usable host cores.  `value` is the all-cores figure in
+    the unit of the metric, i.e. SCALED BY PIXEL COUNT to a 736 x 1280 image: that scaling FLATTERS the CPU - the reference
+    itself measured 0.0028 images/s at 736 x 1280 on 8 threads because its working set leaves the caches, which a
+    bounded sample cannot show.  `value_config0` is the unscaled measurement."""
+    import statistics
     import fdn_oracle as O
     from weights import synth_state_dict
     from common import fdn_shapes, lpnet_weights
-    cores = usable_cores()
-    torch.set_num_threads(cores)
     P = synth_state_dict(fdn_shapes(), 7, prefix_key="fdn/", tame=0.03)
     PL = lpnet_weights()
     x = torch.rand(1, 3, h, w, generator=torch.Generator().manual_seed(0))
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        r = O.lpnet_forward(PL, x)
-        O.fdn_forward(P, x, r)
-        dt = time.perf_counter() - t0
+
+    def one():
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            r = O.lpnet_forward(PL, x)
+            O.fdn_forward(P, x, r)
+            return time.perf_counter() - t0
+
+    cores = usable_cores()
+    runs = {}
+    for n in sorted({min(8, cores), cores}):
+        torch.set_num_threads(n)
+        one()                                                  # warm-up (allocator, oneDNN / MKL plans)
+        runs[n] = sorted(one() for _ in range(3))
+    dt = statistics.median(runs[cores])
     px_ratio = (h * w) / (736.0 * 1280.0)
-    return {"value": px_ratio / dt, "unit": "images/s (736x1280-equivalent, scaled by pixel count from the sample)", "cores": cores,
-            "kind": "port", "value_config0": 1.0 / dt, "unit_config0": f"images/s at {h}x{w} (BASELINE.json configs[0], unscaled)",
-            "sample": f"1 image {h}x{w} fp32, LPNet+FDN oracle forward, {dt:.2f} s wall"}
+    out = {"value": px_ratio / dt, "unit": "images/s (736x1280-equivalent: the sample SCALED BY PIXEL COUNT, which flatters the CPU)",
+           "cores": cores, "kind": "port", "value_config0": 1.0 / dt,
+           "unit_config0": f"images/s at {h}x{w} (BASELINE.json configs[0], unscaled)",
+           "protocol": "1 warm-up + median of 3",
+           "by_threads": {str(n): {"images_per_s_config0": 1.0 / statistics.median(v), "seconds": [round(t, 3) for t in v]} for n, v in runs.items()},
+           "reference_720p_note": "the reference itself: 0.0028 images/s at 736x1280 on 8 threads in the build container (SURVEY.md 6)",
+           "sample": f"1 image {h}x{w} fp32, LPNet+FDN oracle forward, median {dt:.2f} s wall at {cores} threads"}
+    return out
 
 
 def free_port():
@@ -366,9 +420,13 @@ def main():
     ap.add_argument("--variant", choices=("lolblur", "lolv1"), default="lolblur",
                     help="lolblur = FDN (BASELINE.json's metric); lolv1 = FDN_lolv1, dim 24 (SURVEY.md 8(f) rank 1)")
     ap.add_argument("--no-affinity", action="store_true", help="do not pin the ranks of a multi-GPU run to NUMA-local cores")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the per-rank step from ONE captured HIP graph (all sub-batch streams inside it) instead of ~2,400 "
-                         "eager launches: takes the Python launch work off the host (eight ranks share one host's cores)")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=True,
+                    help="(default) replay the per-rank step from ONE captured HIP graph instead of ~2,400 eager launches: same kernels, "
+                         "same results bit for bit, and the host issues one hipGraphLaunch per step (eight ranks share one host's cores). "
+                         "The capture happens in this process before the warm-up steps and is not timed")
+    ap.add_argument("--eager", dest="graph", action="store_false", help="issue every launch from Python instead of replaying the captured graph")
+    ap.add_argument("--config", choices=("fdn", "lpnet"), default="fdn",
+                    help="fdn = LPNet -> FDN (the metric); lpnet = I_predict_net alone on the same batch (BASELINE.json configs[4] / SURVEY 8d C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -426,9 +484,32 @@ def main():
         x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
         mk = lambda r: make_input(a.batch, a.height, a.width, dev, seed=1000 + r)
         forward = lambda t: forward_streams(net, lp, t, a.streams)     # LPNet -> FDN on one stream (--streams > 1: experiments, see above)
+        if a.config == "lpnet":
+            def forward(t):                                            # C5: the second arch alone
+                with torch.no_grad():
+                    return lp(t)
         if a.graph:
-            from fdn_hip.pipeline import GraphedStep
-            forward = GraphedStep(net, lp, a.streams)
+            if a.config == "lpnet":
+                eager_lp = forward
+                g_lp = {}
+
+                def forward(t):
+                    if "g" not in g_lp:
+                        g_lp["x"] = t.clone()
+                        for _ in range(2):
+                            eager_lp(g_lp["x"])
+                        torch.cuda.synchronize()
+                        g_lp["g"] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_lp["g"]):
+                            g_lp["out"] = eager_lp(g_lp["x"])
+                    g_lp["x"].copy_(t)
+                    g_lp["g"].replay()
+                    return g_lp["out"]
+            else:
+                from fdn_hip.pipeline import GraphedStep
+                forward = GraphedStep(net, lp, a.streams)
+            forward(x)                                                 # capture now: same process, before the warm-up, untimed
+            torch.cuda.synchronize()
         sync = torch.cuda.synchronize
     B, _, H, W = x.shape
     root_in = root_out = None
@@ -477,21 +558,30 @@ def main():
         assert ok, "dry run: gathered outputs differ from the root's own forward"
 
     roof = top = entries = None
+    prof = None
     if rank == 0 and not a.no_roofline and not a.dry_run:
         agg = None
         for _ in range(2):                                          # the first instrumented pass also pays one-off host costs
             with KernelTimer() as kt:
                 with torch.no_grad():
-                    net(x, ratio_i=lp(x), device=dev)               # single stream: events bracket each launch
+                    if a.config == "lpnet":
+                        lp(x)
+                    else:
+                        net(x, ratio_i=lp(x), device=dev)           # single stream: events bracket each launch
             cur = kt.summary()
             agg = cur if agg is None else {k: (v if v[2] <= agg.get(k, v)[2] else agg[k]) for k, v in cur.items()}
         total_ms = sum(v[2] for v in agg.values())
-        traffic = pmc_traffic_by_group([B, a.height, a.width], a.dtype)
+        prof = matching_profile([B, a.height, a.width], a.dtype) if (a.config == "fdn" and a.variant == "lolblur") else None
+        traffic = {k: v["hbm_bytes_per_launch"] for k, v in prof["groups"].items()} if prof else {}
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][2])
         top = []
         for key, rec in ranked[:3]:
             r_ = kernel_roofline(key, rec, traffic)
             r_["share_of_step"] = rec[2] / total_ms
+            g_ = prof["groups"].get(key) if prof else None
+            if g_ and "simd_time_frac" in g_:                       # what actually bounds it: issue time of the two pipes (committed PMC passes)
+                r_["simd_busy_from_profile"] = {"valu": round(g_["simd_time_frac"]["valu"], 3), "mfma": round(g_["simd_time_frac"]["mfma"], 3),
+                                                "profile": prof["file"], "profile_avg_ms": g_["avg_ms"]}
             top.append(r_)
         roof = dict(top[0])                                         # the dominant INDIVIDUAL kernel
         entries = {}
@@ -512,6 +602,9 @@ def main():
         cfg3 = a.variant == "lolblur" and (a.height, a.width, B) == (1080, 1920, 4) and a.dtype == "bf16"
         if a.dry_run:
             metric, workload = "DRY RUN (CPU/gloo rehearsal, measures nothing)", "dry run"
+        elif a.config == "lpnet":
+            metric = f"images/sec, I_predict_net (LPNet alone) {a.width}x{a.height} bs={B} fp32 [BASELINE.json configs[4], not the headline metric]"
+            workload = f"BASELINE.json configs[4]: LPNet_lolblur forward {a.width}x{a.height} (padded {W}x{H}) batch={B} per GPU fp32, real LPNet_lolblur weights"
         elif a.variant == "lolblur":
             metric = f"images/sec, FDN (LPNet->FDN forward) {a.width}x{a.height} bs={B} {'fp32' if a.dtype == 'f32' else 'bf16-storage'}"
             workload = (("BASELINE.json configs[1]: " if headline else "BASELINE.json configs[2]: " if cfg3 else "")
@@ -535,6 +628,15 @@ def main():
                            "mfma_f32_frac": F_ALG_PER_PX * P * (ips / world) / (PEAK_F32_MFMA_TF * 1e12)},
             "roofline": roof, "top_kernels": top, "cpu_baseline": cpu,
         }
+        if a.config == "lpnet":
+            line["whole_path"] = None                               # SURVEY 8(d)'s F_alg / B_alg are the LPNet -> FDN path's
+        elif prof is not None:
+            # SURVEY 8(d) `roofline.measured`: the bytes the step really moved (committed PMC passes of this shape: memory-side
+            # read requests by size + write requests, one forward of B images) over THIS run's step time, against 8 TB/s
+            moved = (prof["total"]["read_GB"] + prof["total"]["write_GB"]) * 1e9
+            line["whole_path"].update({"hbm_measured_frac": moved / (dt / a.steps) / (PEAK_HBM_GBS * 1e9), "hbm_measured_GB_per_step": moved / 1e9,
+                                       "hbm_measured_over_algorithmic": moved / (B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * B),
+                                       "hbm_measured_profile": prof["file"]})
         if dt_nosg is not None:
             line["without_collectives"] = {"value": imgs / dt_nosg, "ms_per_step": dt_nosg / a.steps * 1e3,
                                            "note": "the same K steps with every rank's shard already resident (no scatter / gather)"}

@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401  (inference_fdn_lolblur.py uses F.pad from the star import)
 from einops import rearrange  # noqa: F401
 
+import fdn_hip
 from fdn_hip import ACT_LEAKY, ACT_NONE, ACT_SIGMOID, ops
 
 
@@ -80,7 +81,7 @@ class FDSA(nn.Module):
 
     def fused(self, x, ln=None, res=None):
         e = self.expand_dim
-        if x.shape[1] in ops.FDSA_FUSED_C:      # levels 1-2: LayerNorm + to_hidden + core in one launch, no hidden tensor in HBM
+        if x.shape[1] in ops.FDSA_FUSED_C and fdn_hip.matrix_pipe() == "bf16":      # levels 1-2: LayerNorm + to_hidden + core in one launch, no hidden tensor in HBM
             srcs = [self.to_hidden.weight] + ([ln[1], ln[2]] if ln is not None else [])
             wpk = self._c.get("pk" if ln is not None else "pk0", srcs, lambda: ops.fdsa_pack(
                 _w(self.to_hidden.weight), *((ln[1], ln[2]) if ln is not None else (None, None))))
@@ -165,7 +166,7 @@ class FCAFFN(nn.Module):
         if xi.shape[1] in ops.FCAFFN_IN_C and w % 2 == 0:
             t = ops.fcaffn_in(xi, xn, x_img, _w(self.project_in.weight), gam, bet, _w(self.conv1_mul.weight),
                               _w(self.conv3_mul.weight), _w(self.conv1_add.weight), _w(self.conv3_add.weight), x1_ln=ln)
-        elif xi.shape[1] >= ops.FCAFFN_PACKED_MIN_C:          # level 3: the same sub-block on the split-bf16 GEMM, one launch
+        elif xi.shape[1] >= ops.FCAFFN_PACKED_MIN_C and fdn_hip.matrix_pipe() == "bf16":          # level 3: the same sub-block on the split-bf16 GEMM, one launch
             srcs = [self.project_in.weight, self.conv1_mul.weight, self.conv3_mul.weight, self.conv1_add.weight, self.conv3_add.weight]
             wpk = self._c.get("fcpk", srcs, lambda: ops.fcaffn_in_pack(*[_w(p) for p in srcs]))
             t = ops.fcaffn_in_packed(xi, ops.chan_stats(xi), xn, x_img, wpk, gam, bet, x1_ln=ln)
@@ -204,7 +205,7 @@ class TransformerBlock(nn.Module):
             x = self.attn.fused(x, ln=(ops.stats_of(x),) + self.norm1.params(), res=x)
         x = self.ffn.fused(x, ln=(ops.stats_of(x),) + self.norm2.params(), res=x)
         if self.use_light:
-            if (x.shape[1] in ops.FCAFFN_IN_C or x.shape[1] >= ops.FCAFFN_PACKED_MIN_C) and x.shape[3] in ops.ROWS_PLANNED_W:      # norm3 on load: no normalised copy of x
+            if (x.shape[1] in ops.FCAFFN_IN_C or (x.shape[1] >= ops.FCAFFN_PACKED_MIN_C and fdn_hip.matrix_pipe() == "bf16")) and x.shape[3] in ops.ROWS_PLANNED_W:      # norm3 on load: no normalised copy of x
                 x = self.ffn2.fused(x, x_high, x_p, x_img, res=x, ln=(ops.stats_of(x),) + self.norm3.params())
             else:
                 x = self.ffn2.fused(self.norm3(x), x_high, x_p, x_img, res=x)

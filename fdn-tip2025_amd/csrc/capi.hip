@@ -1,7 +1,17 @@
 // ABI bookkeeping for libfdn_hip.so.
 #include "common.hpp"
 
-extern "C" int fdn_abi_version(void) { return 9; }
+#include <atomic>
+extern "C" int fdn_abi_version(void) { return 10; }
+
+// Diagnostic switch: 1 = every matrix product of the path on the fp32 MFMA (the round-2 kernels) instead of the
+// split-bf16 forms on v_mfma_f32_32x32x16_bf16, so that the cross-stream finding can be bisected.  Process-wide, default 0.
+static std::atomic<int> g_matrix_pipe_f32{0};
+extern "C" int fdn_set_matrix_pipe(int fp32_only) {
+    g_matrix_pipe_f32.store(fp32_only ? 1 : 0);
+    return FDN_OK;
+}
+bool fdn_matrix_pipe_f32() { return g_matrix_pipe_f32.load() != 0; }
 
 extern "C" const char* fdn_error_string(int code) {
     switch (code) {

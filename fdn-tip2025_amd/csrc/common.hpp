@@ -22,6 +22,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // (<= 0 on error).  fdn_allow_dynamic_lds: raise a kernel's dynamic-LDS limit once per (kernel, device).
 int fdn_device_cus();
 bool fdn_allow_dynamic_lds(const void* kernel, size_t bytes);
+bool fdn_matrix_pipe_f32();                                   // fdn_set_matrix_pipe(1): no bf16-MFMA kernel is launched
 bool fdn_occupancy(int* blocks_per_cu, const void* kernel, int threads, size_t lds);   // hipOccupancyMaxActiveBlocksPerMultiprocessor, cached
 
 __device__ __forceinline__ float gelu_erf(float x) {

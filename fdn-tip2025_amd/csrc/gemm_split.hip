@@ -565,6 +565,9 @@ __global__ void pack_split_kernel(const float* __restrict__ w, fdn_u32x4* __rest
 
 // FDN_ERR_UNSUPPORTED = not a shape of this kernel (fdn_conv1x1 then picks another)
 int fdn_gemm_split(const fdn_conv1x1_desc& d, hipStream_t s) {
+    if (fdn_matrix_pipe_f32()) return FDN_ERR_UNSUPPORTED;
+    // lanes past the pixel count are masked with a byte offset of 2^31: it must stay outside every descriptor of this kernel
+    if ((unsigned long long)(d.N > d.K ? d.N : d.K) * 4ull * (unsigned long long)d.P > 0x7FFFFFFFull) return FDN_ERR_UNSUPPORTED;
     if (!d.wpk || d.kseg[1] > 0 || d.kseg[2] > 0 || d.act != FDN_ACT_NONE || d.x_bf16 || d.out_bf16) return FDN_ERR_UNSUPPORTED;
     if ((long)d.B * cdiv(d.P, TP) * cdiv(d.N, TN) > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
     // short K, wide N, no epilogue: the activation strip stays in registers and the weights stream
@@ -616,6 +619,7 @@ extern "C" int fdn_fcaffn_in_packed(const float* xi, const float* stats_xi, cons
     FDN_CHECK_ARG(xi && stats_xi && x1 && img && wpk && gamma && beta && out && B > 0 && C > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG((stats1 && gamma1 && beta1) || (!stats1 && !gamma1 && !beta1));
     const long P = (long)H * W;
+    if (fdn_matrix_pipe_f32()) return FDN_ERR_UNSUPPORTED;
     if (C < 96 || (unsigned long long)(C + 4) * 4ull * P > 0x7FFFFFFFull) return FDN_ERR_UNSUPPORTED;      // narrower: fdn_fcaffn_in
     if ((long)B * cdiv(P, TP) * cdiv(C, TN) > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
     SArgs a = {};

@@ -874,6 +874,7 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0);
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     FDN_CHECK_ARG(16ull * E * H * W < 0x80000000ull && 4ull * C * H * W < 0x80000000ull);   // 32-bit byte offsets per image
+    if (fdn_matrix_pipe_f32()) return FDN_ERR_UNSUPPORTED;      // (diagnostic switch: the caller takes fdn_conv1x1 + fdn_fdsa_core)
     FusedArgs a;
     a.x = x; a.xbs = xbs; a.stats = stats; a.wpk = wpk; a.dww = dw_w; a.fftw = fft_w; a.out = out;
     a.E = E; a.H = H; a.W = W;

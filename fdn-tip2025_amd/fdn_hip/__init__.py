@@ -37,7 +37,7 @@ class FdnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 9          # include/fdn_hip.h: bumped on any signature change
+ABI_VERSION = 10         # include/fdn_hip.h: bumped on any signature change
 
 
 def lib_path():
@@ -96,6 +96,23 @@ def set_storage_dtype(name):
 
 def storage_dtype():
     return _storage
+
+
+_matrix_pipe = "bf16"
+
+
+def set_matrix_pipe(name):
+    """"bf16" (default): matrix products as six bf16 products of exactly split fp32 operands on v_mfma_f32_32x32x16_bf16;
+    "f32": the fp32-MFMA forms only (diagnostic: bisecting the cross-stream finding of DESIGN.md 4.7; same results to rounding)."""
+    global _matrix_pipe
+    if name not in ("bf16", "f32"):
+        raise ValueError(f"matrix pipe must be 'bf16' or 'f32', got {name!r}")
+    check(lib().fdn_set_matrix_pipe(int(name == "f32")), "fdn_set_matrix_pipe")
+    _matrix_pipe = name
+
+
+def matrix_pipe():
+    return _matrix_pipe
 
 
 def dev(t, what="tensor"):

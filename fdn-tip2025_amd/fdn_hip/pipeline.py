@@ -14,12 +14,24 @@ profiles/r03_cross_stream_probe.txt).  Within one stream kernels 
 outputs are bit-stable (tests/test_gpu_edge.py::test_single_stream_bit_stable).
 """
 import collections
+import os
 
 import torch
 
 from . import storage_dtype
 
 _streams = {}
+MULTISTREAM_ENV = "FDN_HIP_ALLOW_MULTISTREAM"      # "1": allow n_streams > 1 (experiments; results are NOT bit-stable, see above)
+
+
+def _check_streams(n_streams):
+    """One HIP stream per GPU is the product rule.  More than one is refused unless the caller opts in
+    through the environment: the multi-stream forward is known to return wrong rows on MI355X / ROCm 7.2."""
+    if n_streams > 1 and os.environ.get(MULTISTREAM_ENV) != "1":
+        raise RuntimeError(
+            f"fdn_hip: n_streams={n_streams} refused - kernels of different HIP streams that share the GPU with a bf16-MFMA "
+            f"kernel return wrong rows on MI355X / ROCm 7.2 (DESIGN.md 4.7).  Use one stream per GPU, or set {MULTISTREAM_ENV}=1 "
+            "for experiments (optionally with FDN_HIP_MATRIX_PIPE=f32, the fp32-MFMA build of the 1x1 convs, to bisect).")
 
 
 def _get_streams(device, n):
@@ -32,6 +44,7 @@ def _get_streams(device, n):
 def forward_streams(net, lpnet, x, n_streams=1):
     """result = FDN(x, ratio_i=LPNet(x))[0]; n_streams > 1 splits the batch over HIP streams (see the module note: not
     bit-stable on MI355X / ROCm 7.2, experiments only)."""
+    _check_streams(n_streams)
     B = x.shape[0]
     if n_streams <= 1 or B < n_streams:
         with torch.no_grad():
@@ -52,6 +65,13 @@ def forward_streams(net, lpnet, x, n_streams=1):
     return torch.cat(outs)
 
 
+def weights_signature(*modules):
+    """What a captured graph depends on besides the input shape: the storage mode and every parameter / buffer of the live
+    module trees (count, in-place version counters, addresses)."""
+    ps = [p for m in modules for p in list(m.parameters()) + list(m.buffers())]
+    return (storage_dtype(), len(ps), sum(p._version for p in ps), sum(p.data_ptr() & 0xFFFFFFFF for p in ps))
+
+
 class GraphedForward:
     """LPNet -> FDN captured once per input shape into a HIP graph and replayed (hipGraphLaunch).
 
@@ -68,12 +88,26 @@ class GraphedForward:
         self._graphs = collections.OrderedDict()
         self._seen = collections.OrderedDict()      # shapes met once, not captured yet (a capture costs two forwards + a pool)
 
+    def __deepcopy__(self, memo):
+        """A copy of the model (EMA copy, copy.deepcopy(net)) must not try to copy HIP graphs: the copy starts with none and
+        shares nothing with this instance (run() builds a fresh GraphedForward for a copied net anyway)."""
+        return None
+
+    def __getstate__(self):
+        """pickle / torch.save(net): graphs, static tensors and the back-references stay behind."""
+        return {"warmup": self.warmup}
+
+    def __setstate__(self, st):
+        self.net = self.lpnet = None
+        self.warmup = st.get("warmup", 2)
+        self._graphs = collections.OrderedDict()
+        self._seen = collections.OrderedDict()
+
     def _weights_signature(self):
         """A captured graph holds raw pointers to the weights and to the derived operands built from them (LayerNorm folds,
         packed MFMA operands), and was recorded in ONE storage mode: any in-place update, re-load or replacement of a parameter
         or buffer (the live module tree is re-read on every call) and any change of fdn_hip.storage_dtype() invalidates it."""
-        ps = [p for m in (self.net, self.lpnet) for p in list(m.parameters()) + list(m.buffers())]
-        return (storage_dtype(), len(ps), sum(p._version for p in ps), sum(p.data_ptr() & 0xFFFFFFFF for p in ps))
+        return weights_signature(self.net, self.lpnet)
 
     def _eager(self, x):
         with torch.no_grad():
@@ -122,11 +156,19 @@ class GraphedStep:
     the next call."""
 
     def __init__(self, net, lpnet, n_streams=1):
+        _check_streams(n_streams)
         self.net, self.lpnet, self.n = net, lpnet, n_streams
         self._g = None
+        self._key = None
+        self.captures = 0
 
     def __call__(self, x):
-        if self._g is None or self._x.shape != x.shape:
+        # the graph holds raw pointers to the weights and their derived operands and was recorded in one storage mode on one
+        # device: re-capture when any of them changed (as GraphedForward does), not only when the input shape did
+        key = (tuple(x.shape), x.device.index, weights_signature(self.net, self.lpnet))
+        if self._g is None or self._key != key:
+            self._key = key
+            self.captures += 1
             self._x = x.clone()
             for _ in range(2):                       # FFT tables, weight caches, stream pool: built outside the capture
                 forward_streams(self.net, self.lpnet, self._x, self.n)
@@ -149,7 +191,7 @@ def run(net, lpnet, x):
     B, _, H, W = x.shape
     if B * H * W < GRAPH_BELOW_PIXELS:
         g = net.__dict__.get("_fdn_graphed")
-        if g is None or g.lpnet is not lpnet:
+        if g is None or g.lpnet is not lpnet or g.net is not net:
             g = net.__dict__["_fdn_graphed"] = GraphedForward(net, lpnet)
         return g(x)
     return forward_streams(net, lpnet, x, 1)

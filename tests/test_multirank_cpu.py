@@ -124,3 +124,72 @@ def test_bench_launcher_ends_promptly_when_a_rank_dies():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--dry-run"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and time.time() - t0 < 120
+
+
+class _FakeDist:
+    """Records how sharding drives the collectives (no process group needed)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def get_rank(self):
+        return 0
+
+    def scatter(self, out, lst, src=0, async_op=None):
+        self.calls.append(("scatter", async_op))
+        out.copy_(lst[0])
+
+    def gather(self, t, lst, dst=0, async_op=None):
+        self.calls.append(("gather", async_op))
+        lst[0].copy_(t)
+
+
+def test_sharded_step_is_strictly_serial():
+    """scatter -> forward -> gather never overlap.  Both collectives are issued blocking (async_op=False
+    explicitly, so a later "optimisation" to async prefetch has to delete this test), in that order, around the forward."""
+    sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+    from fdn_hip import sharding
+    d = _FakeDist()
+    order = []
+    x = torch.arange(6.0).view(2, 3)
+    bufs = [torch.empty(2, 3)]
+
+    def fwd(t):
+        order.append(list(d.calls))
+        return t * 2
+
+    sharding.sharded_step(d, fwd, torch.empty(2, 3), [x], bufs)
+    assert d.calls == [("scatter", False), ("gather", False)]
+    assert order == [[("scatter", False)]]                      # the forward ran after the scatter and before the gather
+    assert torch.equal(bufs[0], x * 2)
+
+
+def test_second_stream_is_refused_without_opt_in(monkeypatch):
+    """the multi-stream forward is known to corrupt rows on MI355X / ROCm 7.2: it raises
+    unless FDN_HIP_ALLOW_MULTISTREAM=1, in forward_streams and in GraphedStep, before anything touches a GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+    import pytest
+    from fdn_hip import pipeline
+    monkeypatch.delenv(pipeline.MULTISTREAM_ENV, raising=False)
+    with pytest.raises(RuntimeError, match="n_streams=3 refused"):
+        pipeline.forward_streams(None, None, torch.zeros(6, 3, 8, 8), n_streams=3)
+    with pytest.raises(RuntimeError, match="refused"):
+        pipeline.GraphedStep(None, None, n_streams=2)
+    monkeypatch.setenv(pipeline.MULTISTREAM_ENV, "1")
+    pipeline.GraphedStep(None, None, n_streams=2)               # opt-in: constructs (nothing runs here)
+
+
+def test_graphed_forward_does_not_travel_with_copies():
+    """copy.deepcopy / pickle of a model that has run through pipeline.run must not try to copy HIP graphs."""
+    import copy
+    import pickle
+    sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+    from fdn_hip import pipeline
+    net, lp = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+    g = pipeline.GraphedForward(net, lp)
+    g._graphs["k"] = (object(), None, None, None)               # stands for a captured graph
+    net.__dict__["_fdn_graphed"] = g
+    c = copy.deepcopy(net)
+    assert c.__dict__.get("_fdn_graphed") is None
+    st = pickle.loads(pickle.dumps(g))
+    assert st.net is None and len(st._graphs) == 0
