@@ -81,6 +81,21 @@ class FDSA(nn.Module):
 
     def fused(self, x, ln=None, res=None):
         e = self.expand_dim
+        norms = (self.norm1, self.norm2, self.norm3)
+        gam = self._c.get("g", [n.body.weight for n in norms], lambda: torch.cat([n.body.weight.detach() for n in norms]))
+        bet = self._c.get("b", [n.body.bias for n in norms], lambda: torch.cat([n.body.bias.detach() for n in norms]))
+        if (ops.FDSA_FULL and x.shape[1] in ops.FDSA_FUSED_C and x.shape[1] <= ops.FDSA_FULL_MAX_C and fdn_hip.matrix_pipe() == "bf16"
+                and fdn_hip.storage_dtype() == "f32" and (res is None or res.is_contiguous())):
+            # levels 1-2: the whole sub-block in one launch - no hidden tensor and no (out1|out2|out3|v_value) hand-off in HBM
+            srcs = [self.to_hidden.weight, self.project_out.weight] + [n.body.weight for n in norms] + [n.body.bias for n in norms] \
+                + ([ln[1], ln[2]] if ln is not None else [])
+            wfull = self._c.get("full" if ln is not None else "full0", srcs, lambda: ops.fdsa_full_pack(
+                _w(self.to_hidden.weight), *((ln[1], ln[2]) if ln is not None else (None, None)), _w(self.project_out.weight), gam, bet))
+            if wfull is not None:
+                y = ops.fdsa_full(x, ln[0] if ln is not None else None, wfull, _w(self.to_hidden_dw.weight), _w(self.fft), res=res,
+                                  want_stats=res is not None)
+                if y is not None:
+                    return y
         if x.shape[1] in ops.FDSA_FUSED_C and fdn_hip.matrix_pipe() == "bf16":      # levels 1-2: LayerNorm + to_hidden + core in one launch, no hidden tensor in HBM
             srcs = [self.to_hidden.weight] + ([ln[1], ln[2]] if ln is not None else [])
             wpk = self._c.get("pk" if ln is not None else "pk0", srcs, lambda: ops.fdsa_pack(
@@ -90,9 +105,6 @@ class FDSA(nn.Module):
         else:
             hidden = ops.conv1x1(x, _w(self.to_hidden.weight), ln=ln, cache=(self._c, "th"))
             o = ops.fdsa_core(hidden, _w(self.to_hidden_dw.weight), _w(self.fft))
-        norms = (self.norm1, self.norm2, self.norm3)
-        gam = self._c.get("g", [n.body.weight for n in norms], lambda: torch.cat([n.body.weight.detach() for n in norms]))
-        bet = self._c.get("b", [n.body.bias for n in norms], lambda: torch.cat([n.body.bias.detach() for n in norms]))
         y = ops.fdsa_out(o, _w(self.project_out.weight), gam, bet, res=res, want_stats=res is not None)   # levels 1, 2
         if y is not None:
             return y

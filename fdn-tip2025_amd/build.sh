@@ -8,7 +8,7 @@ BUILD=${BUILD:-build}
 mkdir -p fdn_hip "$BUILD"
 # The SLP vectoriser pairs fp32 ops into v_pk_* at the price of v_mov shuffles and ~45 more VGPRs; the
 # VALU-issue-bound kernels listed here measure faster without it (fdffn_mid 2.35 -> 1.89 ms at level 1).
-NOSLP="patchfft ffn_tail"
+NOSLP="patchfft ffn_tail fdsa_full"
 OBJS=""
 PIDS=""
 NEWEST_HDR=$(ls -t csrc/*.hpp csrc/*.inc ../include/fdn_hip.h build.sh | head -1)

@@ -858,13 +858,16 @@ extern "C" int fdn_fdffn_mid(const void* x_, const float* w0, const float* w2, c
     return fdn_launch_status();
 }
 
-extern "C" int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, fdn_stream_t stream) {
-    FDN_CHECK_ARG(w && wpk && C > 0 && C % 2 == 0 && E > 0 && (!gamma == !beta));
-    const int nch = (E + FEG - 1) / FEG;
-    const int total = nch * (((C + 15) / 16) * 3 + 1) * 64;
-    hipLaunchKernelGGL(fdsa_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma, beta,
-                       reinterpret_cast<fdn_u32x4*>(wpk), C, E, nch);
+// the operand image for nch8 >= ceil(E / 8) chunks of 8 channels (chunks past E are zeros): fdn_fdsa_full walks 16-channel chunks at C > 32
+int fdn_fdsa_pack_chunks(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, int nch8, hipStream_t s) {
+    FDN_CHECK_ARG(w && wpk && C > 0 && C % 2 == 0 && E > 0 && (!gamma == !beta) && nch8 * FEG >= E);
+    const int total = nch8 * (((C + 15) / 16) * 3 + 1) * 64;
+    hipLaunchKernelGGL(fdsa_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, gamma, beta, reinterpret_cast<fdn_u32x4*>(wpk), C, E, nch8);
     return fdn_launch_status();
+}
+
+extern "C" int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, fdn_stream_t stream) {
+    return fdn_fdsa_pack_chunks(w, gamma, beta, wpk, C, E, (E + FEG - 1) / FEG, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,

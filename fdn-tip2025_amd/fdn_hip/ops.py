@@ -250,6 +250,44 @@ def fdsa_fused(x, stats, wpk, dw_w, fft_w, out_dtype=torch.float32):
     return out
 
 
+FDSA_FULL = False           # True: the whole FDSA sub-block in one launch (fdn_fdsa_full) for C <= FDSA_FULL_MAX_C; False: fdn_fdsa_fused + fdn_fdsa_out
+FDSA_FULL_MAX_C = 32        # measured (tools/ab_fdsa_full.py, B = 8 720p shapes): one launch 3.52 against 3.77 ms at C = 32 and 2.89 against 2.93 at
+                            # C = 24 (8 x 16 tiles, 8-channel chunks); at C = 48 / 64 (8 x 8 tiles, 16-channel chunks) it loses, 2.63 against 2.25 ms
+
+
+def fdsa_full_pack(w_hidden, gamma, beta, w_out, gamma3, beta3):
+    """Operand image of fdn_fdsa_full: to_hidden (+ the LayerNorm in front) and project_out (+ norm1..3) as split-bf16 MFMA operands.
+    None when the library has no form for this width."""
+    E4, C = w_hidden.shape[0], w_hidden.shape[1]
+    E = E4 // 4
+    nbytes = lib().fdn_fdsa_full_pack_bytes(C, E)
+    if nbytes <= 0:
+        return None
+    wpk = torch.empty(nbytes, device=w_hidden.device, dtype=torch.uint8)
+    check(lib().fdn_fdsa_full_pack(_flat(w_hidden.reshape(E4, C), "w_hidden"), _flat(gamma, "gamma"), _flat(beta, "beta"),
+                                   _flat(w_out.reshape(w_out.shape[0], 3 * E), "w_out"), _flat(gamma3, "gamma3"), _flat(beta3, "beta3"),
+                                   ctypes.c_void_p(wpk.data_ptr()), C, E, stream()), "fdn_fdsa_full_pack")
+    return wpk
+
+
+def fdsa_full(x, stats, wpk, dw_w, fft_w, res=None, want_stats=False):
+    """x [B,C,H,W] -> res + project_out(norm1..3(FDSA core(LN(x))) * v_value) in ONE launch (fdn_fdsa_full).  Returns None when the
+    library has no form for the shape (the caller takes fdsa_fused + fdsa_out)."""
+    B, C, H, W = x.shape
+    E = fft_w.shape[0]
+    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    st = torch.empty((B, 1, 2, H * W), device=x.device, dtype=torch.float32) if want_stats else None
+    ptr, xbs = _planes(x, "x")
+    rc = lib().fdn_fdsa_full(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), ctypes.c_void_p(wpk.data_ptr()), _flat(dw_w, "dw_w"),
+                             _flat(fft_w, "fft_w"), _flat(res, "res"), _flat(out, "out"), _flat(st, "stats_out"), B, C, E, H, W, stream())
+    if rc == 4:                 # FDN_ERR_UNSUPPORTED
+        return None
+    check(rc, "fdn_fdsa_full")
+    if want_stats:
+        out._fdn_stats = st
+    return out
+
+
 def fdsa_out(o, w, gamma3, beta3, res=None, want_stats=False):
     """Fused FDSA tail (fdn_fdsa_out).  Returns None when the size is not covered (E > 76 or N > 64)."""
     B, C4, H, W = o.shape

@@ -132,6 +132,22 @@ int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* 
 int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
                    void* out, int B, int C, int E, int H, int W, int out_bf16, fdn_stream_t stream);
 
+/* The WHOLE FDSA sub-block in one launch (FDN_arch.py:575-639, the LayerNorm of :668 in front and the residual add of :671 behind):
+ * fdn_fdsa_fused and fdn_fdsa_out in one kernel, without the [B][4E][H][W] tensor between them - C planes in, C planes out.
+ * The three LayerNorms over E are applied AFTER project_out through sums that are linear in the channels (pivot-shifted, so nothing
+ * cancels: csrc/fdsa_full.hip has the algebra and its error bound); results agree with the two-kernel route to fp32 rounding.
+ * fdn_fdsa_full_pack: to_hidden w_hidden [4E][C] (+ optional LayerNorm gamma, beta [C] of the input), project_out w_out [C][3E],
+ *   gamma3 / beta3 [3E] of norm1|norm2|norm3 -> wpk (fdn_fdsa_full_pack_bytes(C, E) bytes; 0 = unsupported width).
+ * fdn_fdsa_full: x [B][C][H][W] (batch stride xbs), stats [B][2][P] = (mean, rstd) of x or NULL (then pack without gamma / beta),
+ *   dw_w [4E][9], fft_w [E][8][5], res [B][C][H][W] or NULL -> out [B][C][H][W] = res + project_out(...); stats_out [B][2][P] or NULL =
+ *   (mean, rstd) of out over C.  C in {24, 32, 48, 64}, E <= int(1.2 C), H % 8 == 0, W % 16 == 0 (C <= 32) or W % 8 == 0; anything
+ *   else (and fdn_set_matrix_pipe(1)) returns FDN_ERR_UNSUPPORTED: use fdn_fdsa_fused + fdn_fdsa_out. */
+long fdn_fdsa_full_pack_bytes(int C, int E);
+int fdn_fdsa_full_pack(const float* w_hidden, const float* gamma, const float* beta, const float* w_out, const float* gamma3,
+                       const float* beta3, void* wpk, int C, int E, fdn_stream_t stream);
+int fdn_fdsa_full(const float* x, long xbs, const float* stats, const void* wpk, const float* dw_w, const float* fft_w,
+                  const float* res, float* out, float* stats_out, int B, int C, int E, int H, int W, fdn_stream_t stream);
+
 /* FDSA tail in one launch (FDN_arch.py:633-639 and the residual add of :671): norm1/2/3 over the E channels
  * of out1|out2|out3, times v_value, project_out (3E -> N) + res, and (optionally) the channel LayerNorm
  * statistics of the result.  o [B][4E][P] as written by fdn_fdsa_core; w [N][3E]; gamma3,beta3 [3E];

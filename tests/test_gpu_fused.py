@@ -87,12 +87,14 @@ def test_fdsa_fused_batch_slices_and_edges(A):
 
 
 @pytest.mark.xfail(strict=False, reason="multi-stream runs are not bit-stable on MI355X / ROCm 7.2 beside bf16-MFMA kernels (DESIGN.md 4.7)")
-def test_forward_streams_cold_start(A):
-    """A freshly constructed model driven from three HIP streams at once: the derived weights (LayerNorm folds, packed
+def test_forward_streams_cold_start(A, monkeypatch):
+    """(opt-in experiment: FDN_HIP_ALLOW_MULTISTREAM=1; the strict test of the event ordering is test_weight_cache_event_ordering)
+    A freshly constructed model driven from three HIP streams at once: the derived weights (LayerNorm folds, packed
     MFMA operands, BN folds) are built on whichever stream gets there first and every other stream must wait for them
     (the first multi-stream call used to race)."""
     from basicsr.models.archs.LPNet_arch import I_predict_net
-    from fdn_hip.pipeline import forward_streams
+    from fdn_hip.pipeline import MULTISTREAM_ENV, forward_streams
+    monkeypatch.setenv(MULTISTREAM_ENV, "1")
 
     def fresh():
         net = A.FDN()
@@ -109,6 +111,33 @@ def test_forward_streams_cold_start(A):
     ref = forward_streams(net2, lp2, x, 1)
     torch.cuda.synchronize()
     assert torch.equal(cold, ref)
+
+
+def test_weight_cache_event_ordering(A):
+    """STRICT: a WeightCache entry built on one HIP stream is event-ordered before another stream reads it, without any
+    kernel of this library overlapping another (the overlap is what DESIGN.md 4.7 forbids; the ordering is what a cold model driven
+    from a second stream relies on).  The build enqueues a long fill in front of the value on stream A; stream B hits the entry
+    at once and copies it: the copy must hold the final value."""
+    from fdn_hip import ops
+    c = ops.WeightCache()
+    src = torch.nn.Parameter(torch.ones(4, device="cuda:0"))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.zeros(64 << 20, device="cuda:0")
+
+    def build():
+        for _ in range(20):
+            big.add_(1.0)                       # ~ milliseconds of work queued in front of the value
+        return big[:1024] * 0 + 7.0
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        va = c.get("k", [src], build)
+    with torch.cuda.stream(sb):
+        vb = c.get("k", [src], build)           # same entry, other stream: must wait for A's event
+        got = vb.clone()
+    torch.cuda.synchronize()
+    assert va is vb and bool((got == 7.0).all())
+    hit = c._store["k"]
+    assert sa.cuda_stream in hit[3] and sb.cuda_stream in hit[3]
 
 
 @pytest.mark.parametrize("C,H,W,B", [(32, 16, 40, 2), (32, 33, 66, 1), (64, 24, 24, 2), (64, 7, 130, 1), (32, 368, 640, 1)])

@@ -482,11 +482,12 @@ MULTISTREAM = pytest.mark.xfail(strict=False, reason="MI355X / ROCm 7.2: a kerne
 
 
 @MULTISTREAM
-def test_forward_streams_bit_identical(A):
-    """Splitting the batch over HIP streams (fdn_hip.pipeline, experiments only) returns exactly the single-stream result -
-    when the platform issue named above does not strike (at this size the sub-batches rarely overlap)."""
+def test_forward_streams_bit_identical(A, monkeypatch):
+    """Splitting the batch over HIP streams (fdn_hip.pipeline, experiments only: FDN_HIP_ALLOW_MULTISTREAM=1) returns exactly the
+    single-stream result - when the platform issue named above does not strike (at this size the sub-batches rarely overlap)."""
     from basicsr.models.archs.LPNet_arch import I_predict_net
-    from fdn_hip.pipeline import forward_streams
+    from fdn_hip.pipeline import MULTISTREAM_ENV, forward_streams
+    monkeypatch.setenv(MULTISTREAM_ENV, "1")
     net = load(A.FDN(), fdn_weights(tame=0.03))
     lp = load(I_predict_net(), lpnet_weights())
     x = dev(torch.rand(4, 3, 64, 96, generator=torch.Generator().manual_seed(21)))
@@ -494,6 +495,35 @@ def test_forward_streams_bit_identical(A):
     two = forward_streams(net, lp, x, 2)
     torch.cuda.synchronize()
     assert torch.equal(one, two)
+
+
+def test_forward_streams_fp32_pipe_bit_identical(A, monkeypatch):
+    """STRICT counterpart and A/B of the finding above: with fdn_hip.set_matrix_pipe("f32") no kernel issues
+    v_mfma_f32_32x32x16_bf16, and the three-stream forward at a size where the sub-batches DO overlap (6 x 256 x 256: 7-8 of 8 runs
+    wrong on the bf16 pipe) must equal the one-stream forward bit for bit, every time.  This is the strict test of the multi-stream
+    host logic (stream pool, WeightCache events, record_stream), and the bisection that pins the corruption on the bf16 MFMA."""
+    import fdn_hip
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from fdn_hip.pipeline import MULTISTREAM_ENV, forward_streams
+    monkeypatch.setenv(MULTISTREAM_ENV, "1")
+    net = load(A.FDN(), fdn_weights(tame=0.03))
+    lp = load(I_predict_net(), lpnet_weights())
+    x = dev(torch.rand(6, 3, 256, 256, generator=torch.Generator().manual_seed(22)))
+    fdn_hip.set_matrix_pipe("f32")
+    try:
+        one = forward_streams(net, lp, x, 1).clone()
+        torch.cuda.synchronize()
+        bad = 0
+        for _ in range(6):
+            three = forward_streams(net, lp, x, 3)
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(one, three))
+    finally:
+        fdn_hip.set_matrix_pipe("bf16")
+    bf = forward_streams(net, lp, x, 1)
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 6 three-stream forwards on the fp32 matrix pipe differ from the one-stream forward"
+    assert O.psnr(bf.cpu(), one.cpu()) > 100.0          # the two matrix pipes agree to fp32 rounding
 
 
 @pytest.mark.parametrize("case", ["a", "b", "c", "d"])
