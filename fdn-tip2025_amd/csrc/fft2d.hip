@@ -1125,6 +1125,14 @@ int launch_cols_planned(const ColArgs& a, long planes, fdn_stream_t stream, bool
         case 17 * 16: return launch_cols_rp<17, 16, MODE>(a, planes, stream);
         case 17 * 8: return launch_cols_rp<17, 8, MODE>(a, planes, stream);
         case 34 * 32: return launch_cols_rp<34, 32, MODE>(a, planes, stream);       // 1088 rows: 1080p level 1
+        // the shapes the reference's own drivers feed: LOL-Blur frames 640 x 1120 (inference_fdn_lolblur.py:16-17, already x32) and
+        // LOL-v1 400 x 600 padded to 416 x 608 (inference_fdn_lolv1.py:52-64)
+        case 20 * 32: return launch_cols_rp<20, 32, MODE>(a, planes, stream);
+        case 20 * 16: return launch_cols_rp<20, 16, MODE>(a, planes, stream);
+        case 20 * 8: return launch_cols_rp<20, 8, MODE>(a, planes, stream);
+        case 13 * 32: return launch_cols_rp<13, 32, MODE>(a, planes, stream);
+        case 13 * 16: return launch_cols_rp<13, 16, MODE>(a, planes, stream);
+        case 13 * 8: return launch_cols_rp<13, 8, MODE>(a, planes, stream);
         default: break;
     }
     *done = false;
@@ -1511,6 +1519,8 @@ bool rows_plan(int W, int* R1, int* P) {
     for (int r : {20, 30})
         for (int p : {32, 16, 8})
             if (W == 2 * r * p) { *R1 = r; *P = p; return true; }
+    for (int p : {16, 8})                                   // LOL-v1 padded: W = 608 / 304 (19 x 16, 19 x 8; 152 = 2 x 19 x 4 stays generic)
+        if (W == 2 * 19 * p) { *R1 = 19; *P = p; return true; }
     return false;
 }
 #define FDN_ROWS_DISPATCH(CALL)                                        \
@@ -1521,6 +1531,8 @@ bool rows_plan(int W, int* R1, int* P) {
         case 30 * 64 + 32: return CALL(30, 32);                        \
         case 30 * 64 + 16: return CALL(30, 16);                        \
         case 30 * 64 + 8: return CALL(30, 8);                          \
+        case 19 * 64 + 16: return CALL(19, 16);                        \
+        case 19 * 64 + 8: return CALL(19, 8);                          \
         default: break;                                                \
     }
 
@@ -1528,7 +1540,7 @@ bool rows_plan(int W, int* R1, int* P) {
 
 extern "C" int fdn_fft_prepare(int n) {
     FDN_CHECK_ARG(n > 0);
-    for (int R : {23, 17})
+    for (int R : {23, 17, 20, 13})
         for (int P : {32, 16, 8})
             if (n == R * P && !get_table_rp(R, P)) return FDN_ERR_LAUNCH;      // column lengths with a compile-time plan
     if (n == 34 * 32 && !get_table_rp(34, 32)) return FDN_ERR_LAUNCH;

@@ -431,7 +431,7 @@ def rfft_rows(x, pitch=None):
     return out
 
 
-ROWS_PLANNED_W = tuple(2 * r * p for r in (20, 30) for p in (32, 16, 8))     # widths fdn_rfft_rows_ln has a form for
+ROWS_PLANNED_W = tuple(2 * r * p for r in (20, 30) for p in (32, 16, 8)) + (608, 304)     # widths fdn_rfft_rows_ln has a form for (19 x 16, 19 x 8: LOL-v1 padded)
 
 
 def rfft_rows_ln(x, stats, gamma, beta, pitch=None):

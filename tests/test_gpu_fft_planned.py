@@ -11,7 +11,7 @@ from common import rel_rms
 
 pytestmark = pytest.mark.gpu
 
-PLANNED_H = [736, 368, 184, 544, 272, 136, 1088]
+PLANNED_H = [736, 368, 184, 544, 272, 136, 1088, 640, 320, 160, 416, 208, 104]       # + the LOL-Blur (640 x 1120) and padded LOL-v1 (416 x 608) pyramids
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +85,8 @@ def _fcaffn_ref(z, amp, pha, wxa, wxp):
     return torch.view_as_real(torch.fft.ifft(out, dim=2) * Z.shape[2])
 
 
-@pytest.mark.parametrize("H,C,Wf", [(736, 8, 73), (368, 16, 161), (184, 8, 161), (544, 8, 20), (272, 3, 9), (136, 16, 33), (1088, 8, 41)])
+@pytest.mark.parametrize("H,C,Wf", [(736, 8, 73), (368, 16, 161), (184, 8, 161), (544, 8, 20), (272, 3, 9), (136, 16, 33), (1088, 8, 41),
+                                    (640, 8, 57), (320, 16, 33), (160, 8, 141), (416, 8, 305), (208, 3, 153), (104, 16, 77)])
 def test_cols_fcaffn_matches_reference_math(ops, H, C, Wf):
     B = 2
     z = _rnd(B, C, H, Wf, 2, seed=H)
@@ -128,7 +129,7 @@ def test_sincos_whole_float_range(ops):
     assert torch.isnan(sn).all() and torch.isnan(cs).all()
 
 
-PLANNED_W = [1280, 640, 320, 1920, 960, 480]
+PLANNED_W = [1280, 640, 320, 1920, 960, 480, 608, 304]
 
 
 @pytest.mark.parametrize("W", PLANNED_W)
@@ -165,7 +166,7 @@ def test_rows_round_trip_at_bench_shape(ops):
     assert rel_rms(back.cpu(), x) < 2e-6
 
 
-@pytest.mark.parametrize("C,H,W", [(32, 9, 1280), (64, 5, 640), (8, 11, 320), (3, 4, 960)])
+@pytest.mark.parametrize("C,H,W", [(32, 9, 1280), (64, 5, 640), (8, 11, 320), (3, 4, 960), (24, 6, 608), (48, 5, 304)])
 def test_rfft_rows_ln_equals_layernorm_then_rfft(ops, C, H, W):
     """Row r2c with the channel LayerNorm applied on load against fdn_layernorm_chan -> fdn_rfft_rows and against float64."""
     B = 2
