@@ -44,6 +44,28 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * (x >= 0.f ? 1.0f - pe : pe);
 }
 
+// The same GELU on a PAIR of values: the polynomial, the argument scaling and the final products run as packed fp32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: ~4.5 issue cycles for two lanes of work against 4 for one), the two reciprocals and the two
+// exponentials stay scalar: 21 instructions per pair instead of 30.  Bit-identical to gelu_fast per component.
+typedef float fdn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fdn_f32x2 gelu_fast2(fdn_f32x2 x) {
+    const fdn_f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const fdn_f32x2 den = __builtin_elementwise_fma(ax, fdn_f32x2(0.3275911f * 0.70710678118654752440f), fdn_f32x2(1.0f));
+    const fdn_f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    fdn_f32x2 p = __builtin_elementwise_fma(t, fdn_f32x2(0.5f * 1.061405429f), fdn_f32x2(0.5f * -1.453152027f));
+    p = __builtin_elementwise_fma(t, p, fdn_f32x2(0.5f * 1.421413741f));
+    p = __builtin_elementwise_fma(t, p, fdn_f32x2(0.5f * -0.284496736f));
+    p = __builtin_elementwise_fma(t, p, fdn_f32x2(0.5f * 0.254829592f));
+    const fdn_f32x2 poly = t * p;
+    const fdn_f32x2 u = x * 0.84932180028801904272f;
+    const fdn_f32x2 u2 = u * u;
+    const fdn_f32x2 ex = {__builtin_amdgcn_exp2f(-u2.x), __builtin_amdgcn_exp2f(-u2.y)};
+    const fdn_f32x2 pe = poly * ex;
+    const fdn_f32x2 om = 1.0f - pe;
+    const fdn_f32x2 f = {x.x >= 0.f ? om.x : pe.x, x.y >= 0.f ? om.y : pe.y};
+    return x * f;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     // act is wave-uniform: every test below is a scalar compare-and-branch PER VALUE, so the common kinds come first (the
     // switch form walked ~8 branches even for FDN_ACT_NONE).  Kernels with long epilogues resolve act once per tile instead.

@@ -109,8 +109,14 @@ __device__ __forceinline__ void dw_gate_rows(const float* ta, const float* tb0, 
                 g1 = fmaf(wb1[dy * 3 + dx], SAME ? p[k][dx] : q[k][dx], g1);
             }
         if (i < rows_ok) {                                                   // wave-uniform
+#ifndef FDN_GELU_SCALAR
+            const fdn_f32x2 ge = gelu_fast2(fdn_f32x2{s0, s1}) * fdn_f32x2{g0, g1};      // both channels of the pair in packed fp32
+            st_store1<OBF>(ge.x, rout, voff0, plane0 + (unsigned)i * row4);
+            if (has1) st_store1<OBF>(ge.y, rout, voff0, plane1 + (unsigned)i * row4);
+#else
             st_store1<OBF>(gelu_fast(s0) * g0, rout, voff0, plane0 + (unsigned)i * row4);
             if (has1) st_store1<OBF>(gelu_fast(s1) * g1, rout, voff0, plane1 + (unsigned)i * row4);
+#endif
         }
     }
 }

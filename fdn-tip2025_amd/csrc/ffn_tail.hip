@@ -363,6 +363,33 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         load_row(0, 0);
         load_row(1, 1);
         load_row(2, 2);
+#ifndef FDN_GELU_SCALAR
+        static_assert(R % 2 == 0, "rows are gated in pairs");
+#pragma unroll
+        for (int i = 0; i < R; i += 2) {                                            // two rows per trip: their GELU runs in packed fp32
+            float sA[2], sB[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int ii = i + h2;
+                if (ii + 3 < R + 2) load_row(ii + 3, (ii + 3) & 3);
+                sA[h2] = 0.f, sB[h2] = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int k = (ii + dy) & 3;
+                        sA[h2] = fmaf(wa[dy * 3 + dx], wA_[k][dx], sA[h2]);
+                        sB[h2] = fmaf(wb[dy * 3 + dx], wB_[k][dx], sB[h2]);
+                    }
+            }
+            const fdn_f32x2 val = gelu_fast2(fdn_f32x2{sA[0], sA[1]}) * fdn_f32x2{sB[0], sB[1]};      // gelu(x1) * x2, FDN_arch.py:473 / :427
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val.x, acc[i][t], 0, 0, 0);
+                acc[i + 1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val.y, acc[i + 1][t], 0, 0, 0);
+            }
+        }
+#else
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             if (i + 3 < R + 2) load_row(i + 3, (i + 3) & 3);
@@ -379,6 +406,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val, acc[i][t], 0, 0, 0);
         }
+#endif
         if (more) {
             stash(buf ^ 1, nxt);                             // (that half was last read two pairs ago, behind the previous barrier)
 #pragma unroll

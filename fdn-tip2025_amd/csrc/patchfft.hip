@@ -252,7 +252,10 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
 constexpr int LS2 = 73;            // odd: lanes walking rows (ring) or (row, patch) pairs (row FFT) hit distinct banks
 constexpr int LSM = 67;
 
-constexpr int CPB = 4;                                  // channels per workgroup (software-pipelined)
+// channels per workgroup (software-pipelined), chosen per launch: as many as leave ~8 rounds of workgroups on the chip, 4 .. 22.  Round 4,
+// interleaved A/B at B = 8 720p: 4 channels 1.702 ms, 8 1.666, 11 1.654, 22 1.646 (level 2: 0.877 / 0.846 / 0.846 / 0.837) - fewer, longer
+// workgroups: the fp32 form loses its time to workgroup turnover behind the store path, not inside the waves (profiles/r04_mid_pmc.txt)
+constexpr int CPB_MIN = 4, CPB_MAX = 22;
 constexpr int HALO2 = (TH + 4) * (TW + 4);
 constexpr int HPT2 = (HALO2 + 255) / 256;               // 10 elements per thread
 
@@ -263,7 +266,7 @@ template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as 
 __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                            const float* __restrict__ w2, const float* __restrict__ ffta,
                                                            const float* __restrict__ fftp, float* __restrict__ out, int Hd,
-                                                           int H, int W, int tiles_x, int ntiles) {
+                                                           int H, int W, int tiles_x, int ntiles, int CPB) {
     __shared__ float tin[(TH + 4) * LS2 + 4];       // halo 2 (+ spare cells)
     __shared__ float mid[(TH + 2) * LSM];           // gelu(dw0(x)) on halo 1
     __shared__ __attribute__((aligned(16))) float2 S[NP * PS];
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
     // waited for with vmcnt(0), which also drains the halo prefetch issued just before (the counter is in-order)
     const int ftid = tid < 40 ? tid : 0;
     float fa = ffta[cbase * 40 + ftid], fp = fftp[cbase * 40 + ftid];
+    const bool ring_inside = ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + TW + 1 <= W;
     for (int ci = 0; ci < CPB; ++ci) {
         const int c = cbase + ci;
         if (c >= Hd) break;                                   // uniform
@@ -385,6 +389,17 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) o8[j] = fmaf(k0[dy * 3 + dx], v[j + dx], o8[j]);
             }
+#ifndef FDN_GELU_SCALAR
+            if (ring_inside) {                                    // uniform: the whole ring of this tile lies in the image (all but border tiles)
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {                  // GELU on pairs: packed fp32 for the polynomial and the products
+                    const fdn_f32x2 gv = gelu_fast2(fdn_f32x2{o8[j], o8[j + 1]});
+                    mid[r * LSM + c0 + j] = gv.x;
+                    mid[r * LSM + c0 + j + 1] = gv.y;
+                }
+                return;
+            }
+#endif
             const int y = ty0 - 1 + r;
             const bool yok = y >= 0 && y < H;
 #pragma unroll
@@ -847,14 +862,24 @@ extern "C" int fdn_fdffn_mid(const void* x_, const float* w0, const float* w2, c
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
     // (the 16-byte-lane halo fetch, V4 = true, measured slower here - 1.95 vs 1.80 ms at level 1: this kernel is bound by
     // VALU issue, and the float4 stash costs four LDS writes per load)
-    const dim3 grid((unsigned)(tx * ty) * ((Hd + CPB - 1) / CPB) * B);
     const int nt = tx * ty;
+    int CPB = CPB_MIN;
+    {
+        const int cus = fdn_device_cus();
+        if (cus <= 0) return FDN_ERR_LAUNCH;
+        const long want = 8L * 3 * cus;                                    // ~8 rounds of three workgroups per CU
+        long groups = (want + (long)nt * B - 1) / ((long)nt * B);         // channel groups per (image, tile) that reach it
+        const long gmin = (Hd + CPB_MAX - 1) / CPB_MAX, gmax = (Hd + CPB_MIN - 1) / CPB_MIN;
+        groups = groups < gmin ? gmin : (groups > gmax ? gmax : groups);
+        CPB = (int)((Hd + groups - 1) / groups);
+    }
+    const dim3 grid((unsigned)nt * ((Hd + CPB - 1) / CPB) * B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // (a two-channels-per-thread packed-fp32 form measured slower - occupancy - see tools/experiments/fdffn_mid_pair_kernel.hip.inc)
-    if (x_bf16 && out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
-    else if (x_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
-    else if (out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, false, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
-    else hipLaunchKernelGGL((fdffn_mid_kernel<false, false, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt);
+    if (x_bf16 && out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt, CPB);
+    else if (x_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, true, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt, CPB);
+    else if (out_bf16) hipLaunchKernelGGL((fdffn_mid_kernel<false, false, true>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt, CPB);
+    else hipLaunchKernelGGL((fdffn_mid_kernel<false, false, false>), grid, dim3(256), 0, s, x, w0, w2, ffta, fftp, out, Hd, H, W, tx, nt, CPB);
     return fdn_launch_status();
 }
 
