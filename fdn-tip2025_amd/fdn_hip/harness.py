@@ -68,14 +68,19 @@ def lolv1_ratio(x, lp_ratio):
 
 
 @torch.no_grad()
-def enhance_u8(net, lpnet, img_u8, bgr=True, ratio_mode="lolblur"):
+def enhance_u8(net, lpnet, img_u8, bgr=True, ratio_mode="lolblur", ratio=None):
     """uint8 in -> uint8 out through LPNet -> FDN (the body of the reference's per-image loop, batched).
     ratio_mode: "lolblur" feeds LPNet's prediction (inference_fdn_lolblur.py:69-71), "lolv1" feeds
-    mean(gray)/prediction (inference_fdn_lolv1.py:57-62)."""
-    if ratio_mode not in ("lolblur", "lolv1"):
+    mean(gray)/prediction (inference_fdn_lolv1.py:57-62), "fixed" feeds the caller's `ratio` [B,1] and skips LPNet - the
+    ratio sweep of inference_fdn_multi_r.py:78-84 (`ratio = ratio / ratio * i`)."""
+    if ratio_mode not in ("lolblur", "lolv1", "fixed"):
         raise ValueError(f"ratio_mode {ratio_mode!r}")
     x, h, w = preprocess(img_u8, bgr=bgr)
-    if ratio_mode == "lolblur":
+    if ratio_mode == "fixed":
+        if ratio is None or tuple(ratio.shape) != (x.shape[0], 1):
+            raise FdnHipError(f"ratio_mode 'fixed' needs ratio [B,1] for B = {x.shape[0]}")
+        result = net(x, ratio_i=ratio.to(device=x.device, dtype=torch.float32).contiguous(), device=x.device)[0]
+    elif ratio_mode == "lolblur":
         from .pipeline import run
         result = run(net, lpnet, x)                # hipGraph replay for small frames, the eager forward otherwise
     else:

@@ -38,9 +38,11 @@ def load_params(path):
     return sd["params"] if isinstance(sd, dict) and "params" in sd else sd     # inference_fdn_lolblur.py:28,31
 
 
-def main():
-    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--fdn", required=True, help="FDN checkpoint ({'params': state_dict}, 1503 keys)")
+def run_driver(doc, build_models, ratio_mode="lolblur", fdn_keys="FDN checkpoint ({'params': state_dict}, 1503 keys)"):
+    """The directory walk shared by the LOL-Blur and LOL-v1 drivers: build_models() -> (FDN-like module, LPNet module) on the CPU,
+    ratio_mode as fdn_hip.harness.enhance_u8 takes it."""
+    ap = argparse.ArgumentParser(description=doc, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--fdn", required=True, help=fdn_keys)
     ap.add_argument("--lpnet", required=True, help="LPNet checkpoint (292 keys)")
     ap.add_argument("--input", required=True, help="glob of input frames")
     ap.add_argument("--output", required=True, help="output directory")
@@ -52,15 +54,14 @@ def main():
     ap.add_argument("--device", default="cuda:0")
     a = ap.parse_args()
 
-    from basicsr.models.archs.FDN_arch import FDN
-    from basicsr.models.archs.LPNet_arch import I_predict_net
     from fdn_hip.harness import enhance_u8
 
     dev = torch.device(a.device)
     torch.cuda.set_device(dev)
-    net = FDN().to(dev).eval()
+    net, lp = build_models()
+    net = net.to(dev).eval()
     net.load_state_dict(load_params(a.fdn), strict=True)
-    lp = I_predict_net().to(dev).eval()
+    lp = lp.to(dev).eval()
     lp.load_state_dict(load_params(a.lpnet), strict=True)
 
     paths = sorted(glob.glob(a.input))
@@ -80,7 +81,7 @@ def main():
             if not pending:
                 return
             batch = torch.from_numpy(np.stack([im for _, im in pending])).to(dev, non_blocking=True)
-            out = enhance_u8(net, lp, batch, bgr=False).cpu().numpy()
+            out = enhance_u8(net, lp, batch, bgr=False, ratio_mode=ratio_mode).cpu().numpy()
             for (p, _), o in zip(pending, out):
                 writers.append(pool.submit(write_rgb, dest[p], o))
             pending.clear()
@@ -93,6 +94,14 @@ def main():
         for w in writers:
             w.result()
     print(f"{len(paths)} frames -> {a.output}")
+
+
+def main():
+    def build():
+        from basicsr.models.archs.FDN_arch import FDN
+        from basicsr.models.archs.LPNet_arch import I_predict_net
+        return FDN(), I_predict_net()
+    run_driver(__doc__, build)
 
 
 if __name__ == "__main__":

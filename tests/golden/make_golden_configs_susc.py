@@ -15,8 +15,8 @@ error and these evaluations' errors at THAT window (+ a floor of a few ulp); not
 Which bins an evaluation trips over depends on its arithmetic (the fp32 oracle trips at window 18 in every run, the reference never,
 the HIP path at window 24 in four of five runs), so the windows of ONE implementation's evaluations are not the whole ill-conditioned
 set.  `noise64` measures the conditioning itself, independent of any fp32 implementation: the float64 oracle is run with the rounding
-of an fp32 FFT emulated on every forward transform of the path - rfft2 output + 2e-7 * rms(|z| of the transformed patch / plane) *
-(randn + i randn), the error level of an fp32 8x8 or full-image FFT - with n noise seeds, and the per-window RMS deviation from the
+of an fp32 FFT emulated on every forward transform of the path - rfft2(t + 2e-7 * rms(t) * randn), the backward-error form of an fp32
+8x8 or full-image FFT - with n noise seeds, and the per-window RMS deviation from the
 clean float64 truth is stored (`y_susc_noise`: [n, 64]).  A window that moves by 1e-6 under that noise is a window where ANY fp32
 evaluation may land 1e-6 away from the truth.
 """
@@ -56,10 +56,11 @@ def main_noise(n):
         gen = torch.Generator().manual_seed(500 + k)
 
         def noisy_rfft2(t, *a, **kw):
-            zc = real_rfft2(t, *a, **kw)
-            rms = zc.abs().pow(2).mean(dim=(-2, -1), keepdim=True).sqrt()
-            nz = torch.randn(zc.shape + (2,), generator=gen, dtype=torch.float64)
-            return zc + 2e-7 * rms * torch.view_as_complex(nz)
+            # backward-error model of an fp32 FFT: the exact transform of a slightly perturbed REAL input (white noise of 2e-7 of the
+            # input's rms per transformed patch / plane) - the noise then has the Hermitian structure of a real transform (a noise
+            # term added to the spectrum itself puts imaginary parts on the self-conjugate bins and flips the +-pi phases MAR mixes)
+            rms = t.pow(2).mean(dim=(-2, -1), keepdim=True).sqrt()
+            return real_rfft2(t + 2e-7 * rms * torch.randn(t.shape, generator=gen, dtype=torch.float64), *a, **kw)
         torch.fft.rfft2 = noisy_rfft2
         try:
             with torch.no_grad():

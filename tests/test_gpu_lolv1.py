@@ -1,6 +1,8 @@
 """GPU parity of the LOL-v1 variant (FDN_lolv1, dim 24: SURVEY.md section 8 (f) rank 1) against the oracle and the
 reference-generated fixtures of tests/golden/make_golden_lolv1.py.  Same tolerance policy as test_gpu_parity.py.
 The widths exercise the odd shapes of the kernels: E = 28/57/115 (FDSA), Hd = 64/129/259 (FDFFN), K = 24/48/96."""
+import os
+
 import pytest
 import torch
 
@@ -28,6 +30,10 @@ def dev(t):
 def load(mod, sd):
     mod.load_state_dict(sd, strict=True)
     return mod.to("cuda:0").eval()
+
+
+def dev_u8(arr):
+    return torch.from_numpy(arr).to("cuda:0").contiguous()
 
 
 def truth(fn, sd, *xs):
@@ -93,3 +99,49 @@ def test_lolv1_harness_u8(L):
     out = harness.enhance_u8(net, lp, img, bgr=True, ratio_mode="lolv1").cpu().numpy()[0]
     diff = out.astype(int) - fx["out_u8"].numpy().astype(int)
     assert abs(diff).max() <= 1 and (diff != 0).mean() < 1e-2
+
+
+def test_drivers_lolv1_and_ratio_sweep(L, tmp_path, monkeypatch):
+    """The two other callers of the path as command-line drivers (inference_fdn_lolv1.py:52-64, inference_fdn_multi_r.py:52-85): synthetic
+    frames and checkpoints on disk -> PNGs, equal to what fdn_hip.harness.enhance_u8 returns for the same frames."""
+    import sys
+    import numpy as np
+    from PIL import Image
+    from basicsr.models.archs.FDN_arch import FDN
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from common import fdn_weights, lpnet_weights
+    from fdn_hip import harness
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fdn-tip2025_amd")
+    monkeypatch.syspath_prepend(pkg)
+    import inference_fdn_lolv1
+    import inference_fdn_multi_r
+    g = torch.Generator().manual_seed(5)
+    frames = [(torch.rand(40, 72, 3, generator=g) * 255).to(torch.uint8).numpy() for _ in range(3)]
+    for i, f in enumerate(frames):
+        Image.fromarray(f, mode="RGB").save(tmp_path / f"low{i}.png")
+    torch.save({"params": lolv1_weights(tame=0.03)}, tmp_path / "fdn_lolv1.pth")
+    torch.save({"params": lpnet_weights("lolv1")}, tmp_path / "lp.pth")
+    torch.save({"params": fdn_weights(tame=0.03)}, tmp_path / "fdn.pth")
+    # LOL-v1 driver
+    monkeypatch.setattr(sys, "argv", ["x", "--fdn", str(tmp_path / "fdn_lolv1.pth"), "--lpnet", str(tmp_path / "lp.pth"),
+                                      "--input", str(tmp_path / "low*.png"), "--output", str(tmp_path / "out"), "--batch", "2"])
+    inference_fdn_lolv1.main()
+    net = load(L.FDN_lolv1(), lolv1_weights(tame=0.03))
+    lp = load(I_predict_net(), lpnet_weights("lolv1"))
+    want = harness.enhance_u8(net, lp, dev_u8(np.stack(frames)), bgr=False, ratio_mode="lolv1").cpu().numpy()
+    for i in range(3):
+        got = np.asarray(Image.open(tmp_path / "out" / f"low{i}.png"))
+        assert np.array_equal(got, want[i])
+    # ratio sweep driver: 4 grid values of one frame
+    monkeypatch.setattr(sys, "argv", ["x", "--fdn", str(tmp_path / "fdn.pth"), "--input", str(tmp_path / "low0.png"), "--output",
+                                      str(tmp_path / "multi_r"), "--start", "0.2", "--stop", "0.6", "--step", "0.1", "--batch", "3"])
+    inference_fdn_multi_r.main()
+    vals = inference_fdn_multi_r.sweep_values(0.2, 0.6, 0.1)
+    net32 = load(FDN(), fdn_weights(tame=0.03))
+    for v in vals:
+        got = np.asarray(Image.open(tmp_path / "multi_r" / inference_fdn_multi_r.output_name(v)))
+        want1 = harness.enhance_u8(net32, None, dev_u8(frames[0][None]), bgr=False, ratio_mode="fixed",
+                                   ratio=torch.tensor([[float(v)]], dtype=torch.float32)).cpu().numpy()[0]
+        assert np.array_equal(got, want1)
+    outs = [np.asarray(Image.open(tmp_path / "multi_r" / inference_fdn_multi_r.output_name(v))).astype(np.int32) for v in vals]
+    assert any(np.abs(outs[0] - o).max() > 0 for o in outs[1:])          # the ratio does steer the result

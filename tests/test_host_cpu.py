@@ -169,3 +169,17 @@ def test_sincos_large_argument_table():
         sn = (s, c, -s, -c)[q]
         cs = (c, -s, -c, s)[q]
         assert abs(sn - math.sin(float(x))) < 1e-12 and abs(cs - math.cos(float(x))) < 1e-12, float(x)
+
+
+def test_ratio_sweep_grid_and_names_follow_the_reference():
+    """inference_fdn_multi_r.py:55,84: `for i in np.arange(0, 1, 0.01)` ... `"./multi_r/{}.png".format(i)` - the driver's grid and the
+    file names it writes are exactly those (format of the numpy float64 loop variable)."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+    import inference_fdn_multi_r as M
+    vals = M.sweep_values(0.0, 1.0, 0.01)
+    ref = [i for i in np.arange(0, 1, 0.01)]
+    assert len(vals) == 100 and all(float(a) == float(b) for a, b in zip(vals, ref))
+    assert [M.output_name(v) for v in vals[:3]] == ["{}.png".format(i) for i in ref[:3]] == ["0.0.png", "0.01.png", "0.02.png"]
+    assert M.output_name(vals[29]) == "{}.png".format(ref[29])
