@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def read_rgb(path):
     from PIL import Image
     with Image.open(path) as im:
-        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+        return np.array(im.convert("RGB"), dtype=np.uint8)           # (a copy: PIL hands out a read-only buffer)
 
 
 def write_rgb(path, arr):
