@@ -11,7 +11,9 @@ err(HIP, f64) <= 4 * err(reference fp32, f64) + floor - a window may only be far
 is far from the truth.  `sens` adds `*_sens64`: the same windows of truth(x + d) - truth(x) for d = 6e-8 * randn (one fp32 ulp of
 the input, seed 5) evaluated in float64 - how strongly each window amplifies a rounding-sized perturbation (the FDSA
 recombination divides by |q| and |k|, SURVEY.md fact 9: a few spots of a frame amplify by 1e3 and more).  A window may be as far
-from the truth as that amplification explains, and no further.  Nothing here is read by the product path.
+from the truth as that amplification explains, and no further.  (Result: 6e-8 in every window - an INPUT perturbation is not what moves the
+ill-conditioned windows, the rounding inside the blocks is; the committed fixture therefore carries make_golden_configs_susc.py's measures instead and
+the `*_sens64` arrays were dropped from it.)  Nothing here is read by the product path.
 """
 import os
 import sys

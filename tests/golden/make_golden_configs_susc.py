@@ -1,7 +1,7 @@
 """Which windows of the configs[1] frame are ill-conditioned IN FP32 (build container, ~7 minutes of CPU per evaluation).
 
     python tests/golden/make_golden_configs_susc.py [n_evaluations, default 4]          # fp32 oracle evaluations  -> *_susc
-    python tests/golden/make_golden_configs_susc.py noise64 [n, default 4]              # float64 + emulated FFT rounding -> *_susc_noise
+    python tests/golden/make_golden_configs_susc.py noise64 [n, default 4] [first seed] # float64 + emulated FFT rounding -> *_susc_noise
 
 The FDSA recombination divides by |q| and |k| and replaces spectrum bins below 1e-10 (FDN_arch.py:593-607): where a bin sits
 near such a point, an fp32 evaluation lands on either side depending on its rounding, and the window around it moves by 1e-6 ..
@@ -40,8 +40,8 @@ def crop(t, org, size):
     return torch.stack([t[0, :, y:y + size, x:x + size] for y, x in org.tolist()])
 
 
-def main_noise(n):
-    """float64 oracle with emulated fp32 FFT rounding (see the module docstring)."""
+def main_noise(n, first=0):
+    """float64 oracle with emulated fp32 FFT rounding (see the module docstring); first > 0 appends seeds first .. first + n - 1."""
     torch.set_num_threads(int(os.environ.get("FDN_GOLDEN_THREADS", "6")))
     z = np.load(os.path.join(HERE, "fdn_tamed_736x1280.npz"))
     out_path = os.path.join(HERE, "fdn_tamed_736x1280_f64.npz")
@@ -51,8 +51,8 @@ def main_noise(n):
     P = O.cast_params(fdn_weights(tame=float(z["tame"])), torch.float64)
     ratio = torch.from_numpy(z["ratio"]).double()
     real_rfft2 = torch.fft.rfft2
-    rows = {k: [] for k in ("y", "q1", "q2", "q3")}
-    for k in range(n):
+    rows = {k: ([r for r in have[k + "_susc_noise"]] if first > 0 and k + "_susc_noise" in have else []) for k in ("y", "q1", "q2", "q3")}
+    for k in range(first, first + n):
         gen = torch.Generator().manual_seed(500 + k)
 
         def noisy_rfft2(t, *a, **kw):
@@ -105,6 +105,6 @@ def main(n):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "noise64":
-        main_noise(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+        main_noise(int(sys.argv[2]) if len(sys.argv) > 2 else 4, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     else:
         main(int(sys.argv[1]) if len(sys.argv) > 1 else 4)

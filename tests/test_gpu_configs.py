@@ -3,8 +3,9 @@
 * configs[0]  one 256 x 256 crop through the inference_fdn_lolblur.py plumbing (LPNet_lolblur.pth -> ratio -> FDN): against the
               reference's own outputs (tests/golden/make_golden_configs.py, fixture fdn_tamed_256).
 * configs[1]  the 720p frame reflect-padded to 736 x 1280: against the reference's own forward on that frame - 64 seeded windows
-              of each of the four outputs plus whole-tensor moments (fixture fdn_tamed_736x1280).  A wrong level-2 / level-3 stage
-              hook-up that only shows at the planned-FFT shapes fails here.
+              of each of the four outputs plus whole-tensor moments (fixture fdn_tamed_736x1280) - and against a float64 truth of the
+              same windows with a per-window conditioning-aware bound (fixture fdn_tamed_736x1280_f64).  A wrong level-2 / level-3
+              stage hook-up that only shows at the planned-FFT shapes, or a localized fault in a few windows, fails here.
 * configs[2]  1088 x 1920 in bf16-storage mode: FDSA / FDFFN blocks against the fp32 oracle at that size with the bf16 bound of
               tests/test_gpu_bf16.py, the whole net at B = 4 for determinism and batch independence.
 """
@@ -66,8 +67,25 @@ def test_config0_256_crop_matches_reference(A):
 
 
 def test_config1_736x1280_frame_matches_reference(A):
-    """The reference's forward on the padded 720p frame (it takes ~6 minutes on the CPU; stored as windows + moments)."""
+    """The reference's forward on the padded 720p frame (it takes ~6 minutes on the CPU; stored as 64 seeded windows of each output +
+    whole-tensor moments), judged WINDOW BY WINDOW against a float64 truth with a conditioning-aware bound - no pooled PSNR, no allowance.
+
+    Every fp32 evaluation of this network sits ~3e-8 (RMS, output scale 0.6) from the float64 truth in a typical 32 x 32 window of `y`, and 1e-7 ..
+    7e-6 away in a few: where a spectrum bin of an FDSA block lies within rounding of 0 (|q|, |k| -> 0) or of the 1e-10 threshold of
+    replace_denormals (FDN_arch.py:593-607), the phase of that bin - and the patch around it - is decided by the evaluation's rounding.  WHICH
+    windows an evaluation trips over depends on its arithmetic (the reference: window 31; the fp32 oracle: 18, 54, 31 ...; this path: 24, 18,
+    31, 54), but WHERE it can happen is a property of the frame, measured in the build container independently of any fp32 implementation
+    (tests/golden/make_golden_configs_susc.py): `y_susc` = per-window error of five fp32 oracle evaluations (the frame and four one-ulp
+    perturbations of it), `y_susc_noise` = per-window deviation of the float64 oracle when every forward FFT is given the backward error of an
+    fp32 transform (input + 2e-7 rms white noise), four seeds - which reproduces the discrete flips of the fp32 evaluations to three digits
+    (window 24: 7.22e-6 in noise seed 1 and in this path; window 18: 6.21e-6 in seed 2 and in the fp32 oracle).  The bound per window w:
+
+        err(HIP, f64)[w]  <=  4 * max( err(reference fp32, f64)[w], y_susc[:, w], y_susc_noise[:, w] )  +  floor
+
+    i.e. a window may be as far from the truth as four times what fp32 is KNOWN to do at that window, and a deviation anywhere else - a tile edge,
+    one block of one level - fails, however few windows it touches.  q1..q3 (MAR, well-conditioned) use the reference's own error alone."""
     z = np.load(os.path.join(GOLDEN, "fdn_tamed_736x1280.npz"))
+    z64 = np.load(os.path.join(GOLDEN, "fdn_tamed_736x1280_f64.npz"))
     net, lp = _nets(A, float(z["tame"]))
     x = torch.rand(1, 3, 720, 1280, generator=torch.Generator().manual_seed(int(z["x_seed"])))
     x = torch.nn.functional.pad(x, (0, 0, 0, 16), mode="reflect")                 # inference_fdn_lolblur.py:60-63
@@ -76,27 +94,30 @@ def test_config1_736x1280_frame_matches_reference(A):
         ratio = lp(dev(x))
         outs = net(dev(x), ratio_i=ratio, device=torch.device("cuda:0"))
     assert torch.allclose(ratio.cpu(), torch.from_numpy(z["ratio"]), rtol=0, atol=5e-6)
+    FLOOR = 5e-8                                  # absolute RMS, ~1.5 ulp of the 0.6-scale output
+    rms = lambda t: (t ** 2).mean((1, 2, 3)).sqrt()
     for got, key, size in zip(outs, ("y", "q1", "q2", "q3"), (32, 32, 16, 8)):
         got = got.cpu()
         org, win, mom = z[key + "_org"], torch.from_numpy(z[key + "_win"]), torch.from_numpy(z[key + "_mom"])
-        mine = torch.stack([got[0, :, y0:y0 + size, x0:x0 + size] for y0, x0 in org.tolist()])
-        p = O.psnr(mine, win)
+        mine = torch.stack([got[0, :, y0:y0 + size, x0:x0 + size] for y0, x0 in org.tolist()]).double()
+        t64 = torch.from_numpy(z64[key + "_win64"])
+        e_hip, e_ref = rms(mine - t64), rms(win.double() - t64)
+        cap = e_ref.clone()
         if key == "y":
-            # The FDformer output is ill-conditioned in a few spots (|q| or |k| ~ 0 in FDSA): with ONE library,
-            # input + 6e-8 * randn (one ulp) moves 5-11 of the 920 32x32 windows of this frame below 100 dB (worst 69 dB, frame
-            # PSNR 95-98 dB; tools/sensitivity_720p.py, profiles/r03_sensitivity_720p.txt).  Two correct fp32 evaluations
-            # therefore agree to ~95 dB over the frame and far better in the typical window - which is what is asserted.
-            per = sorted(O.psnr(mine[i:i + 1], win[i:i + 1]) for i in range(len(org)))
-            assert per[len(per) // 2] > 135.0, f"736x1280 y: median window PSNR {per[len(per) // 2]:.1f} dB"
-            assert sum(v < 100.0 for v in per) <= 3, f"736x1280 y: {sum(v < 100.0 for v in per)} of {len(per)} windows below 100 dB"
-            assert per[0] > 60.0 and p > 85.0, f"736x1280 y: worst window {per[0]:.1f} dB, all windows {p:.1f} dB"
-        else:
-            assert p > 100.0, f"736x1280 {key}: windows PSNR {p:.1f} dB against the reference's output"
+            cap = torch.maximum(cap, torch.from_numpy(z64["y_susc"]).max(0)[0])
+            cap = torch.maximum(cap, torch.from_numpy(z64["y_susc_noise"]).max(0)[0])
+        bad = (e_hip > 4.0 * cap + FLOOR).nonzero().flatten().tolist()
+        worst = torch.argsort(e_hip, descending=True)[:4].tolist()
+        print(f"736x1280 {key}: median window error vs f64 HIP {e_hip.median():.2e} / reference {e_ref.median():.2e}; largest HIP windows "
+              + ", ".join(f"#{w} {e_hip[w]:.2e} (fp32 can do {cap[w]:.2e} there)" for w in worst))
+        assert not bad, (f"736x1280 {key}: windows {bad} are further from the float64 truth than 4 x what fp32 is known to do there: "
+                         + ", ".join(f"#{w} origin {org[w].tolist()} HIP {e_hip[w]:.2e} cap {cap[w]:.2e}" for w in bad[:6]))
+        assert e_hip.median() <= 2.0 * e_ref.median() + FLOOR, (key, float(e_hip.median()), float(e_ref.median()))
         d = got.double()
         m = torch.stack([d.sum((0, 2, 3)), (d * d).sum((0, 2, 3))])
         n = got.shape[2] * got.shape[3]
         assert ((m[0] - mom[0]).abs() / n).max() < 1e-6, f"{key}: per-channel mean off by {((m[0] - mom[0]).abs() / n).max():.2e}"
-        e_tol = 2e-5 if key == "y" else 1e-6          # (y: the few ill-conditioned spots above carry errors of up to 4e-3)
+        e_tol = 2e-5 if key == "y" else 1e-6          # (y: the ill-conditioned spots above carry errors of up to 4e-3 in single pixels)
         assert ((m[1] - mom[1]).abs() / mom[1]).max() < e_tol, f"{key}: per-channel energy off by {((m[1] - mom[1]).abs() / mom[1]).max():.2e}"
 
 
