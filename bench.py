@@ -89,6 +89,10 @@ def describe_call(name, a):
         ob = 2.0 if _iv(a[12]) else 4.0
         f, b = 2.0 * B * H * W * C * 4 * E, B * H * W * (4.0 * C + ob * 4 * E)
         key = f"fdn_fdsa_fused[C={C},E={E},{H}x{W}{',obf16' if ob == 2.0 else ''}]"
+    elif name == "fdn_fdsa_full":
+        B, C, E, H, W = (_iv(v) for v in a[9:14])
+        f, b = 2.0 * B * H * W * (C * 4 * E + 3 * E * C), 4.0 * B * H * W * (3 * C + 2)
+        key = f"fdn_fdsa_full[C={C},E={E},{H}x{W}]"
     elif name == "fdn_fdsa_core":
         B, E, H, W = (_iv(v) for v in a[4:8])
         b = 4.0 * B * H * W * 8 * E

@@ -3,7 +3,7 @@
 set -u
 OUT=$1; R=$(pwd); mkdir -p "$R/$OUT"
 cd /tmp && export TMPDIR=/tmp
-run() { name=$1; shift; rocprofv3 "$@" --output-format csv -d "$R/$OUT/$name" -o p -- python3 "$R/tools/pmc_fdsa_full.py" 3 > "$R/$OUT/$name.log" 2>&1; }
+run() { name=$1; shift; timeout 300 rocprofv3 "$@" --output-format csv -d "$R/$OUT/$name" -o p -- python3 "$R/tools/pmc_fdsa_full.py" 3 > "$R/$OUT/$name.log" 2>&1; }
 run trace --kernel-trace --stats
 run sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES
 run sq2 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM

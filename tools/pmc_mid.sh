@@ -3,7 +3,7 @@
 set -u
 OUT=$1; R=$(pwd); mkdir -p "$R/$OUT"
 cd /tmp && export TMPDIR=/tmp
-run() { name=$1; shift; rocprofv3 "$@" --output-format csv -d "$R/$OUT/$name" -o p -- python3 "$R/tools/pmc_mid.py" > "$R/$OUT/$name.log" 2>&1; }
+run() { name=$1; shift; timeout 300 rocprofv3 "$@" --output-format csv -d "$R/$OUT/$name" -o p -- python3 "$R/tools/pmc_mid.py" > "$R/$OUT/$name.log" 2>&1; }
 run trace --kernel-trace --stats
 run sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVES
 run sq2 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM

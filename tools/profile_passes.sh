@@ -9,7 +9,8 @@ OUT=$1; shift
 R=$(pwd)
 mkdir -p "$R/$OUT"
 cd /tmp && export TMPDIR=/tmp
-run() { name=$1; shift; FDN_CALL_LOG="$R/$OUT/calls_$name.json" rocprofv3 "$@" --output-format csv -d "$R/$OUT/$name" -o p -- python3 "$R/tools/profile_forward.py" $ARGS > "$R/$OUT/$name.log" 2>&1; }
+# (each pass under its own timeout: a counter group rocprofv3 cannot collect aborts the tool and would otherwise hang until the box's limit)
+run() { name=$1; shift; FDN_CALL_LOG="$R/$OUT/calls_$name.json" timeout 420 rocprofv3 "$@" --output-format csv -d "$R/$OUT/$name" -o p -- python3 "$R/tools/profile_forward.py" $ARGS > "$R/$OUT/$name.log" 2>&1; }
 ARGS="$*"
 run trace --kernel-trace --stats
 run rd --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum

@@ -2,7 +2,7 @@
 # The round's closing measurements on ONE box (run from the repo root on the GPU box): tools/profile_round.sh <tag f32> <tag bf16>
 # rocprofv3 passes of the 720p fp32 forward and of the 1080p B = 4 bf16 forward (tools/profile_passes.sh), merged summaries,
 # then bench.py lines for the headline and the other configurations.  Everything lands under gpurun_out/.
-A=${1:-r03_n}; B=${2:-r03_o}
+A=${1:-r04_n}; B=${2:-r04_o}
 tools/profile_passes.sh gpurun_out/$A > gpurun_out/${A}_passes.log 2>&1
 python tools/profile_merge.py gpurun_out/$A gpurun_out/$A > gpurun_out/${A}_merge.log 2>&1
 tools/profile_passes.sh gpurun_out/$B --height 1080 --width 1920 --batch 4 --dtype bf16 > gpurun_out/${B}_passes.log 2>&1
