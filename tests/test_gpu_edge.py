@@ -139,9 +139,13 @@ def test_level_shapes_fdsa_fdffn_vs_oracle(A, c, H, W):
 
 
 @pytest.mark.parametrize("name,c,H,W", [("fcaffn_c32_32x32", 32, 736, 1280), ("fcaffn_c64_46x40", 64, 368, 640),
-                                        ("fcaffn_c128_16x16", 128, 184, 320), ("fcaffn_c32_32x32", 32, 1088, 1920)])
+                                        ("fcaffn_c128_16x16", 128, 184, 320), ("fcaffn_c32_32x32", 32, 1088, 1920),
+                                        # the reference drivers' own shapes (round 4): LOL-Blur frames 640 x 1120 - planned columns 20 x {32, 16, 8},
+                                        # generic rows - and padded LOL-v1 416 x 608 - columns 13 x {32, 16}, planned rows 19 x {16, 8}
+                                        ("fcaffn_c32_32x32", 32, 640, 1120), ("fcaffn_c64_46x40", 64, 320, 560), ("fcaffn_c128_16x16", 128, 160, 280),
+                                        ("fcaffn_c32_32x32", 32, 416, 608), ("fcaffn_c64_46x40", 64, 208, 304)])
 def test_fcaffn_at_bench_shapes_vs_oracle(A, name, c, H, W):
-    """The modulated column kernel (radix 23 x 736 rows, radix 17 at 1080p) with packed guidance, all three levels."""
+    """The modulated column kernel (radix 23 x 736 rows, radix 17 at 1080p, 20 and 13 at the dataset shapes) with packed guidance, all three levels."""
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     sd = fixture_weights(name, fixture(name)["shapes"])
     m = load(A.FCAFFN(c), sd)
