@@ -141,6 +141,19 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned L, unsigned T) {
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
 }
 
+// The same for a 3-D grid of workgroups whose x axis walks the pixels of a plane (the direct convs of convs.hip): the linear
+// workgroup id x + gx (y + gy z) decides the XCD, so it is the linear id that is remapped and then cut back into (x, y, z).  With the
+// plain order the 256-pixel blocks either side of a halo row sit on different XCDs and every input row is fetched by three L2s
+// (conv2d[32->3] read 3.2x its bytes, profiles/r03_n_summary.txt).
+__device__ __forceinline__ void fdn_xcd_block3(unsigned& bx, unsigned& by, unsigned& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, T = gx * gy * gridDim.z;
+    const unsigned S = xcd_contiguous(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), T);
+    bx = S % gx;
+    const unsigned r = S / gx;
+    by = r % gy;
+    bz = r / gy;
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 STORAGE of block-internal activations (BASELINE.json configs[2]).  bf16 is only a
 // memory format here: a value is widened to fp32 when loaded (exact) and rounded to nearest-even when stored

@@ -26,8 +26,10 @@ struct ConvArgs {
 };
 
 __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
-    const long op = (long)blockIdx.x * 256 + threadIdx.x;
-    const int oc0 = blockIdx.y * OCB, b = blockIdx.z;
+    unsigned bx, by, bz;
+    fdn_xcd_block3(bx, by, bz);                         // every XCD walks a contiguous run of pixel blocks: halo rows stay in one L2
+    const long op = (long)bx * 256 + threadIdx.x;
+    const int oc0 = by * OCB, b = bz;
     const long OP = (long)a.OH * a.OW;
     const bool live = op < OP;
     const int oy = live ? (int)(op / a.OW) : 0, ox = live ? (int)(op - (long)oy * a.OW) : 0;
@@ -75,14 +77,16 @@ __global__ __launch_bounds__(256) void conv2d_kernel(ConvArgs a) {
 template <int S, int OCB_>
 __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
-    const int oc0 = blockIdx.y * OCB_, b = blockIdx.z;
+    unsigned bx, by, bz;
+    fdn_xcd_block3(bx, by, bz);
+    const int oc0 = by * OCB_, b = bz;
     const int nvalid = min(OCB_, a.Cout - oc0);
     for (int i = threadIdx.x; i < a.Cin * 9 * OCB_; i += 256) {
         const int o = i % OCB_, t = (i / OCB_) % 9, ci = i / (OCB_ * 9);
         wl[i] = o < nvalid ? a.w[((long)(oc0 + o) * a.Cin + ci) * 9 + t] : 0.f;
     }
     __syncthreads();
-    const long op = (long)blockIdx.x * 256 + threadIdx.x;
+    const long op = (long)bx * 256 + threadIdx.x;
     const long OP = (long)a.OH * a.OW;
     const bool live = op < OP;
     const int oy = live ? (int)(op / a.OW) : 0, ox = live ? (int)(op - (long)oy * a.OW) : 0;
@@ -144,7 +148,9 @@ __global__ __launch_bounds__(256) void convT_kernel(const float* __restrict__ x,
                                                     const float* __restrict__ bias, float* __restrict__ out, int Cin, int H,
                                                     int W, int Cout, int act) {
     extern __shared__ __attribute__((aligned(16))) float wl[];
-    const int oc0 = blockIdx.y * OCB_, b = blockIdx.z;
+    unsigned bx, by, bz;
+    fdn_xcd_block3(bx, by, bz);
+    const int oc0 = by * OCB_, b = bz;
     const int nvalid = min(OCB_, Cout - oc0);
     for (int i = threadIdx.x; i < Cin * 16 * OCB_; i += 256) {
         const int o = i % OCB_, t = (i / OCB_) % 16, ci = i / (OCB_ * 16);
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256) void convT_kernel(const float* __restrict__ x,
     }
     __syncthreads();
     const int OH = 2 * H, OW = 2 * W;
-    const long op = (long)blockIdx.x * 256 + threadIdx.x;
+    const long op = (long)bx * 256 + threadIdx.x;
     const long OP = (long)OH * OW;
     const bool live = op < OP;
     const int oy = live ? (int)(op / OW) : 0, ox = live ? (int)(op - (long)oy * OW) : 0;
@@ -356,8 +362,10 @@ __global__ __launch_bounds__(256) void conv7x7s2_kernel(ConvArgs a) {
     constexpr int HC = (IC + 1) / 2;                      // 35 columns per parity
     __shared__ float tile[CIN][IR][2][HC + 1];
     __shared__ __attribute__((aligned(16))) float wl[CIN * 49 * COUT];
-    const int tid = threadIdx.x, b = blockIdx.z;
-    const int oy0 = blockIdx.y * TR, ox0 = blockIdx.x * TCW;
+    unsigned bx, by, bz;
+    fdn_xcd_block3(bx, by, bz);
+    const int tid = threadIdx.x, b = bz;
+    const int oy0 = by * TR, ox0 = bx * TCW;
     for (int i = tid; i < CIN * 49 * COUT; i += 256) {
         const int o = i % COUT, t = i / COUT;             // t = ci * 49 + ky * 7 + kx
         wl[i] = a.w[(long)o * CIN * 49 + t];

@@ -1,0 +1,21 @@
+"""Per-entry-point milliseconds of one instrumented forward at the bench shape (bench.py's KernelTimer), best of n: python tools/entry_times.py [n] [entry substrings ...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+flt = sys.argv[2:]
+dev = torch.device("cuda:0")
+net, lp = bench.build_models(dev)
+x = bench.make_input(8, 720, 1280, dev, 1000)
+best = {}
+for _ in range(n + 1):
+    with bench.KernelTimer() as kt, torch.no_grad():
+        net(x, ratio_i=lp(x), device=dev)
+    for k, v in kt.summary().items():
+        if not flt or any(f in k for f in flt):
+            best[k] = min(best.get(k, 1e9), v[2])
+for k, v in sorted(best.items(), key=lambda kv: -kv[1]):
+    print(f"{v:8.3f} ms  {k}")
+print(f"{sum(best.values()):8.3f} ms  total of the listed groups")
