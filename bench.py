@@ -507,7 +507,7 @@ def main():
                             eager_lp(g_lp["x"])
                         torch.cuda.synchronize()
                         g_lp["g"] = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g_lp["g"]):
+                        with torch.cuda.graph(g_lp["g"], capture_error_mode="thread_local"):
                             g_lp["out"] = eager_lp(g_lp["x"])
                     g_lp["x"].copy_(t)
                     g_lp["g"].replay()

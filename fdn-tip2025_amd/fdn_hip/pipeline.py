@@ -21,6 +21,9 @@ import torch
 from . import storage_dtype
 
 _streams = {}
+# Graph captures check only THIS thread's GPU calls: with a process group alive (one rank per GPU) RCCL's watchdog thread polls its events
+# from another thread, which the default ("global") capture mode would take for an illegal call during capture and abort the capture
+CAPTURE_MODE = "thread_local"
 MULTISTREAM_ENV = "FDN_HIP_ALLOW_MULTISTREAM"      # "1": allow n_streams > 1 (experiments; results are NOT bit-stable, see above)
 
 
@@ -122,7 +125,7 @@ class GraphedForward:
                 self.net(static_x, ratio_i=self.lpnet(static_x), device=x.device)
         torch.cuda.current_stream(x.device).wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), torch.no_grad():
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE), torch.no_grad():
             static_out = self.net(static_x, ratio_i=self.lpnet(static_x), device=x.device)[0]
         return g, static_x, static_out, self._weights_signature()
 
@@ -174,7 +177,7 @@ class GraphedStep:
                 forward_streams(self.net, self.lpnet, self._x, self.n)
             torch.cuda.synchronize(x.device)
             self._g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g):
+            with torch.cuda.graph(self._g, capture_error_mode=CAPTURE_MODE):
                 self._out = forward_streams(self.net, self.lpnet, self._x, self.n)
         self._x.copy_(x)
         self._g.replay()
