@@ -5,7 +5,13 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-flt = sys.argv[2:]
+flt = [a for a in sys.argv[2:] if not a.endswith(".so")]
+for a in sys.argv[2:]:
+    if a.endswith(".so"):                     # another build of the same ABI (A/B)
+        sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+        import fdn_hip
+        fdn_hip._LIB_PATH = os.path.abspath(a)
+        print("library:", a)
 dev = torch.device("cuda:0")
 net, lp = bench.build_models(dev)
 x = bench.make_input(8, 720, 1280, dev, 1000)
