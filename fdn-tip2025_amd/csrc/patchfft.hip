@@ -113,13 +113,17 @@ __device__ __forceinline__ void stencil_row8(const float* t, int row, int col0, 
 template <bool V4>
 __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restrict__ hidden, const float* __restrict__ dww,
                                                            const float* __restrict__ fftw, float* __restrict__ out, int E,
-                                                           int H, int W, int tiles_x, int ntiles) {
+                                                           int H, int W, int tiles_x, int ntiles, int EPB) {
     __shared__ float halo[2][(TH + 2) * HS + 4];
     __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
 
     const int tid = threadIdx.x;
-    const unsigned item = xcd_contiguous(blockIdx.x, gridDim.x);           // (b, e, tile), tile fastest
-    const int tile = item % ntiles, e = (item / ntiles) % E, b = item / (ntiles * E);
+    // (round 4) a workgroup walks EPB channels of one tile: fewer, longer workgroups
+    const int ngrp = (E + EPB - 1) / EPB;
+    const unsigned item = xcd_contiguous(blockIdx.x, gridDim.x);           // (b, channel group, tile), tile fastest
+    const int tile = item % ntiles, e_first = ((item / ntiles) % ngrp) * EPB, b = item / (ntiles * ngrp);
+    for (int e = e_first; e < e_first + EPB && e < E; ++e) {
+    if (e != e_first) __syncthreads();                                     // the previous channel's inverse rows have read the spectra
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const unsigned hw4 = (unsigned)H * W * 4u;                  // bytes per plane; 4E planes per image < 4 GB (checked by the host)
     const long base = (long)b * 4 * E * H * W;
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
         irfft8_row(x, r);
         bstore8(r, rout, ooff, (unsigned)(t * E + e) * hw4);
     }
+    }   // channels of this workgroup
 }
 
 // ------------------------------------------------------------------------------------------
@@ -842,12 +847,26 @@ extern "C" int fdn_fdsa_core(const float* hidden, const float* dw_w, const float
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     FDN_CHECK_ARG(16ull * E * H * W < 0x80000000ull);          // one image's 4E planes are addressed with 32-bit byte offsets
     const int tx = cdiv(W, TW), ty = cdiv(H, TH);
+#ifndef FDN_CORE_EPB
+#define FDN_CORE_EPB 0          // 0: chosen per launch
+#endif
+    int EPB = FDN_CORE_EPB;
+    if (EPB <= 0) {
+        const int cus = fdn_device_cus();
+        if (cus <= 0) return FDN_ERR_LAUNCH;
+        const long want = 8L * 3 * cus, per = (long)tx * ty * B;            // ~8 rounds of three workgroups per CU
+        long groups = (want + per - 1) / per;
+        groups = groups < 1 ? 1 : (groups > E ? E : groups);
+        EPB = (int)((E + groups - 1) / groups);
+        if (EPB > 8) EPB = 8;
+    }
+    const int ngrp = (E + EPB - 1) / EPB;
     if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(hidden) & 15) == 0)
-        hipLaunchKernelGGL(fdsa_core_kernel<true>, dim3((unsigned)(tx * ty) * E * B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
-                           fft_w, out, E, H, W, tx, tx * ty);
+        hipLaunchKernelGGL(fdsa_core_kernel<true>, dim3((unsigned)(tx * ty) * ngrp * B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
+                           fft_w, out, E, H, W, tx, tx * ty, EPB);
     else
-        hipLaunchKernelGGL(fdsa_core_kernel<false>, dim3((unsigned)(tx * ty) * E * B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
-                           fft_w, out, E, H, W, tx, tx * ty);
+        hipLaunchKernelGGL(fdsa_core_kernel<false>, dim3((unsigned)(tx * ty) * ngrp * B), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, dw_w,
+                           fft_w, out, E, H, W, tx, tx * ty, EPB);
     return fdn_launch_status();
 }
 
