@@ -224,18 +224,22 @@ __global__ __launch_bounds__(NT) void ffn_tail_kernel(FtArgs a) {
 // tail against 0.9 ms of HBM time for its 150 planes; the gate tensor (C planes written + read: 5 GB at level 1) is gone.
 // ------------------------------------------------------------------------------------------------
 constexpr int SW_TC = 64;                 // tile columns (two 32-column wave strips)
-constexpr int SW_LS = 68;                 // LDS row stride of a halo plane (66 used)
+constexpr int SW_LS = 72;                 // LDS row stride of a halo plane, in (A, B) cells: left halo at 3, interior from 4 (16-byte lanes), right halo at 68
 constexpr unsigned SW_OOB = 0x80000000u;
 
-template <int MT, int R, bool IBF>
+// (round 4) The two source planes of a pair live in LDS as ONE plane of (A, B) cells and the taps as (wA, wB) pairs: a window cell is
+// one 8-byte read and both stencils advance in one v_pk_fma_f32 - 36 packed FMAs per pair and lane where there were 72 scalar ones.
+// CODD (odd C: the two channels of a pair read different B planes, FDN_lolv1's 129) keeps a second plane of (A, B1) cells for the odd lanes.
+template <int MT, int R, bool IBF, bool CODD>
 __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel(FtArgs a) {
     constexpr int HRW = 2 * R + 2;                       // halo rows of the tile
-    constexpr int PLN = HRW * SW_LS + 4;                 // floats per plane (+ spare cells)
+    constexpr int PLN = HRW * SW_LS + 4;                 // cells per plane (+ spare cells for the threads without a lane / an edge cell)
     constexpr int NV4 = HRW * 16;                        // float4 of the 64 interior columns
     constexpr int V4T = (NV4 + 255) / 256;               // per thread
+    constexpr int NPL = CODD ? 2 : 1;
     constexpr unsigned IES = st_bytes<IBF>();
-    __shared__ __attribute__((aligned(16))) float planes[2][3][PLN];
-    __shared__ __attribute__((aligned(16))) float dwl[2][2][20];          // [buffer][k parity][wA(9), pad, wB(9), pad]
+    __shared__ __attribute__((aligned(16))) fdn_f32x2 planes[2][NPL][PLN];
+    __shared__ __attribute__((aligned(16))) fdn_f32x2 dwl[2][2][10];      // [buffer][k parity][tap] = (wA, wB)
 
     const int C = a.C, N = a.N, H = a.H, W = a.W;
     const unsigned P = (unsigned)H * W, hwi = P * IES, hw4 = P * 4u;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
     const int b = item / a.tiles_per_img, t_ = item - b * a.tiles_per_img;
     const int ty0 = (t_ / a.tiles_x) * (2 * R), tx0 = (t_ % a.tiles_x) * SW_TC;
     const rsrc_t rin = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.y) + (long)b * C * P * IES), (unsigned)C * hwi);
-    const bool codd = (C & 1) != 0;
+    constexpr bool codd = CODD;
     const int npairs = (C + 1) / 2;
 
     // ---- loaders: 16-byte lanes for the interior, dwords for the two edge columns (W % 4 == 0: a float4 is inside or outside) ----
@@ -258,14 +262,14 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         const int y = ty0 - 1 + r, xx = tx0 + 4 * c4;
         const bool ok = idx < NV4 && y >= 0 && y < H && xx < W;
         g4[i] = ok ? (unsigned)(y * W + xx) * IES : SW_OOB;
-        s4[i] = idx < NV4 ? r * SW_LS + 1 + 4 * c4 : HRW * SW_LS;
+        s4[i] = idx < NV4 ? r * SW_LS + 4 + 4 * c4 : HRW * SW_LS;
     }
     {
-        const int er = tid >> 1, ec = (tid & 1) ? SW_TC + 1 : 0;
+        const int er = tid >> 1, ec = (tid & 1) ? SW_TC + 1 : 0;      // image column tx0 - 1 + ec lives in cell 3 + ec
         const int ey = ty0 - 1 + er, ex = tx0 - 1 + ec;
         const bool eok = tid < 2 * HRW && ey >= 0 && ey < H && ex >= 0 && ex < W;
         ge = eok ? (unsigned)(ey * W + ex) * IES : SW_OOB;
-        se = tid < 2 * HRW ? er * SW_LS + ec : HRW * SW_LS;
+        se = tid < 2 * HRW ? er * SW_LS + 3 + ec : HRW * SW_LS;
     }
     // two register stages: the planes of pair m + 2 are requested while pair m is evaluated (one pair of arithmetic is ~0.4 us,
     // an HBM round trip under load several times that), parked in LDS a pair later
@@ -288,10 +292,10 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         qe[0] = st_load1<IBF>(rin, ge, (unsigned)pa * hwi);
         qe[1] = st_load1<IBF>(rin, ge, (unsigned)pb0 * hwi);
         if (codd) qe[2] = st_load1<IBF>(rin, ge, (unsigned)pb1 * hwi);
-        if (tid < 40) {                                      // depthwise taps of channels 2m, 2m + 1: [parity][wA | wB]
+        if (tid < 40) {                                      // depthwise taps of channels 2m, 2m + 1: [parity][tap](wA, wB)
             const int par = tid / 20, i = tid - par * 20, j = 2 * m + par;
-            const int tap = i < 10 ? i : i - 10;
-            pdw = (j < C && tap < 9) ? a.wdw[(long)((i < 10 ? 0 : C) + j) * 9 + tap] : 0.f;
+            const int tap = i >> 1;
+            pdw = (j < C && tap < 9) ? a.wdw[(long)(((i & 1) ? C : 0) + j) * 9 + tap] : 0.f;
         }
         const int j = 2 * m + kh;
 #pragma unroll
@@ -302,15 +306,15 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         const float (&qe)[3] = st.qe;
         const float pdw = st.pdw;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            if (pl == 2 && !codd) break;
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
             for (int i = 0; i < V4T; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) planes[buf][pl][s4[i] + e] = q4[pl][i][e];
-            planes[buf][pl][se] = qe[pl];
+                for (int e = 0; e < 4; e += 2)               // 16-byte lanes: cells (A, B)(A, B)
+                    *reinterpret_cast<float4*>(&planes[buf][pl][s4[i] + e]) = float4{q4[0][i][e], q4[1 + pl][i][e], q4[0][i][e + 1], q4[1 + pl][i][e + 1]};
+            planes[buf][pl][se] = fdn_f32x2{qe[0], qe[1 + pl]};
         }
-        if (tid < 40) dwl[buf][tid / 20][tid % 20] = pdw;
+        if (tid < 40) reinterpret_cast<float*>(dwl[buf][tid / 20])[tid % 20] = pdw;
     };
 
     f32x16 acc[R][MT];
@@ -339,26 +343,19 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         const bool more = m + 1 < npairs;
         if (m + 2 < npairs) fetch(m + 2, mine);
         // taps of this lane's channel
-        float wa[9], wb[9];
+        fdn_f32x2 wab[9];
         {
-            const float* dp = dwl[buf][kh];
+            const fdn_f32x2* dp = dwl[buf][kh];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                wa[i] = dp[i];
-                wb[i] = dp[10 + i];
-            }
+            for (int i = 0; i < 9; ++i) wab[i] = dp[i];
         }
-        const float* pA = planes[buf][0] + r0 * SW_LS + col;
-        const float* pB = planes[buf][(codd && kh) ? 2 : 1] + r0 * SW_LS + col;
+        const fdn_f32x2* pAB = planes[buf][(codd && kh) ? NPL - 1 : 0] + r0 * SW_LS + 3 + col;
         // window rows live in a ring of four: row i + 3 is requested while row i (rows i .. i + 2) is evaluated, so the LDS
         // latency hides behind a row's arithmetic
-        float wA_[4][3], wB_[4][3];
+        fdn_f32x2 wAB[4][3];
         auto load_row = [&](int hr, int k) {
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                wA_[k][dx] = pA[hr * SW_LS + dx];
-                wB_[k][dx] = pB[hr * SW_LS + dx];
-            }
+            for (int dx = 0; dx < 3; ++dx) wAB[k][dx] = pAB[hr * SW_LS + dx];
         };
         load_row(0, 0);
         load_row(1, 1);
@@ -367,22 +364,18 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         static_assert(R % 2 == 0, "rows are gated in pairs");
 #pragma unroll
         for (int i = 0; i < R; i += 2) {                                            // two rows per trip: their GELU runs in packed fp32
-            float sA[2], sB[2];
+            fdn_f32x2 sAB[2];
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int ii = i + h2;
                 if (ii + 3 < R + 2) load_row(ii + 3, (ii + 3) & 3);
-                sA[h2] = 0.f, sB[h2] = 0.f;
+                sAB[h2] = fdn_f32x2{0.f, 0.f};
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int k = (ii + dy) & 3;
-                        sA[h2] = fmaf(wa[dy * 3 + dx], wA_[k][dx], sA[h2]);
-                        sB[h2] = fmaf(wb[dy * 3 + dx], wB_[k][dx], sB[h2]);
-                    }
+                    for (int dx = 0; dx < 3; ++dx) sAB[h2] = __builtin_elementwise_fma(wab[dy * 3 + dx], wAB[(ii + dy) & 3][dx], sAB[h2]);
             }
-            const fdn_f32x2 val = gelu_fast2(fdn_f32x2{sA[0], sA[1]}) * fdn_f32x2{sB[0], sB[1]};      // gelu(x1) * x2, FDN_arch.py:473 / :427
+            const fdn_f32x2 val = gelu_fast2(fdn_f32x2{sAB[0].x, sAB[1].x}) * fdn_f32x2{sAB[0].y, sAB[1].y};      // gelu(x1) * x2, FDN_arch.py:473 / :427
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val.x, acc[i][t], 0, 0, 0);
@@ -393,16 +386,12 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             if (i + 3 < R + 2) load_row(i + 3, (i + 3) & 3);
-            float sA = 0.f, sB = 0.f;
+            fdn_f32x2 sAB = {0.f, 0.f};
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int k = (i + dy) & 3;
-                    sA = fmaf(wa[dy * 3 + dx], wA_[k][dx], sA);
-                    sB = fmaf(wb[dy * 3 + dx], wB_[k][dx], sB);
-                }
-            const float val = gelu_fast(sA) * sB;                                   // gelu(x1) * x2, FDN_arch.py:473 / :427
+                for (int dx = 0; dx < 3; ++dx) sAB = __builtin_elementwise_fma(wab[dy * 3 + dx], wAB[(i + dy) & 3][dx], sAB);
+            const float val = gelu_fast(sAB.x) * sAB.y;                                   // gelu(x1) * x2, FDN_arch.py:473 / :427
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val, acc[i][t], 0, 0, 0);
         }
@@ -473,7 +462,8 @@ int launch_sw(FtArgs a, hipStream_t s) {
     a.tiles_x = cdiv(a.W, SW_TC);
     a.tiles_per_img = a.tiles_x * cdiv(a.H, 2 * R);
     a.total_tiles = a.B * a.tiles_per_img;
-    hipLaunchKernelGGL((ffn_tail_sw_kernel<MT, R, IBF>), dim3((unsigned)a.total_tiles), dim3(256), 0, s, a);
+    if (a.C & 1) hipLaunchKernelGGL((ffn_tail_sw_kernel<MT, R, IBF, true>), dim3((unsigned)a.total_tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ffn_tail_sw_kernel<MT, R, IBF, false>), dim3((unsigned)a.total_tiles), dim3(256), 0, s, a);
     return fdn_launch_status();
 }
 
