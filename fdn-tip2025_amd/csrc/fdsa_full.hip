@@ -643,7 +643,7 @@ FullLayout full_layout(int C, int E) {
 }  // namespace
 
 // defined in patchfft.hip: the to_hidden operand image for a given number of 8-channel chunks
-int fdn_fdsa_pack_chunks(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, int nch8, hipStream_t s);
+int fdn_fdsa_pack_chunks(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, int nch8, hipStream_t s, int channel_major);
 
 static bool full_supported(int C, int E) { return (C == 24 || C == 32 || C == 48 || C == 64) && E > 0 && E <= C * 6 / 5; }
 
@@ -660,7 +660,7 @@ extern "C" int fdn_fdsa_full_pack(const float* w_hidden, const float* gamma, con
     const FullLayout L = full_layout(C, E);
     hipStream_t s = static_cast<hipStream_t>(stream);
     fdn_u32x4* base = static_cast<fdn_u32x4*>(wpk);
-    const int rc = fdn_fdsa_pack_chunks(w_hidden, gamma, beta, reinterpret_cast<float*>(base), C, E, L.nch8, s);
+    const int rc = fdn_fdsa_pack_chunks(w_hidden, gamma, beta, reinterpret_cast<float*>(base), C, E, L.nch8, s, 0);
     if (rc != FDN_OK) return rc;
     const long total = L.s1_frag + L.ep_frag;
     hipLaunchKernelGGL(fdsa_full_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w_out, gamma3, beta3, base + L.th_frag,

@@ -545,11 +545,19 @@ struct FusedArgs {
 #ifndef FDN_FUSED_WGS
 #define FDN_FUSED_WGS 2
 #endif
+#ifndef FDN_FUSED_CELLS
+#define FDN_FUSED_CELLS 1
+#endif
 template <int C, bool LN, bool OBF>          // OBF: the (out1|out2|out3|v_value) planes are stored as bf16
 __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArgs a) {
-    __shared__ float hid[32 * FPL + (FDN_FUSED_WGS == 1 ? 2048 : 0)];      // (A/B hook: a pad that leaves room for one workgroup per CU only)
+    // (round 4) C <= 32: the hidden tile is ONE plane per channel of (q, k, v, v_value) CELLS - the MFMA rows of a chunk are channel-major,
+    // so a lane's accumulator holds whole cells - and the taps are (wq, wk, wv, wvv) cells too: a window position is one 16-byte read
+    // and the four depthwise convs advance as two v_pk_fma_f32 (144 packed FMAs per thread and chunk where the three row-phase stencils
+    // took 216 scalar ones and wave 3 ran the fourth beside the column phase).  C >= 48 (108 / 144 registers of strips) keeps the planar form.
+    constexpr bool CELLS = FDN_FUSED_CELLS && (C + 15) / 16 <= 2;
+    __shared__ __attribute__((aligned(16))) float hid[32 * FPL + (FDN_FUSED_WGS == 1 ? 2048 : 0)];      // (A/B hook: a pad that leaves room for one workgroup per CU only)
     __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
-    __shared__ float wks[32 * 9];                                     // depthwise taps of the chunk: [kind * 8 + channel][9]
+    __shared__ __attribute__((aligned(16))) float wks[32 * 9];        // depthwise taps of the chunk: [kind * 8 + channel][9]; CELLS: [channel][tap][kind]
     __shared__ float fgs[FEG * 40];                                   // fft gains of the chunk's channels: [channel][ky][kx]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
@@ -627,6 +635,11 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     float st_w = 0.f, st_w1 = 0.f, st_f0 = 0.f, st_f1 = 0.f;
     auto stage_fetch = [&](int ch) {
         auto tap_of = [&](int i) {                                      // element i < 288: row m = kind * 8 + channel, tap i % 9
+            if constexpr (CELLS) {                                      // ... or (channel, tap, kind)
+                const int cl = i / 36, rem = i - cl * 36;
+                const int ew = ch * FEG + cl;
+                return a.dww[(long)((rem & 3) * E + (ew < E ? ew : E - 1)) * 9 + (rem >> 2)];
+            }
             const int m = i / 9, tap = i - m * 9;
             const int ew = ch * FEG + (m & 7);
             return a.dww[(long)((m >> 3) * E + (ew < E ? ew : E - 1)) * 9 + tap];
@@ -666,9 +679,15 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                 const bool one = (onebits >> si) & 1u;
                 const fdn_u32x4 xone = {one ? 0x3F803F80u : 0u, one ? 0x00003F80u : 0u, 0u, 0u};
                 acc = fdn_mfma_bf16(AW_AHEAD ? aw[KS - 1] : wp_[(KS - 1) * 64], xone, acc);          // + bias: b1 + b2 + b3 against 1, 1, 1 (0 outside the image)
+                // MFMA row R = (r & 3) + 8 (r >> 2) + 4 kh = 4 * channel + kind (fdn_fdsa_pack): registers 4g .. 4g + 3 are one cell of channel 2g + kh
+                if constexpr (CELLS) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    hid[((r & 3) + 8 * (r >> 2) + 4 * kh) * FPL + pixoff[si]] = acc[r];   // row = kind * 8 + channel
+                    for (int g = 0; g < 4; ++g)
+                        reinterpret_cast<f32x4*>(hid)[(2 * g + kh) * FPL + pixoff[si]] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hid[((r & 3) * 8 + 2 * (r >> 2) + kh) * FPL + pixoff[si]] = acc[r];   // plane = kind * 8 + channel
+                }
             }
         }
         if (AW_AHEAD && ch + 1 < a.nchunks) aw_fetch(ch + 1);
@@ -705,14 +724,51 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                     for (int dx = 0; dx < 3; ++dx) o8[j] = fmaf(wkt[dy * 3 + dx], v[j + dx], o8[j]);
             }
         };
+        if constexpr (CELLS) {
+            const f32x4* hc = reinterpret_cast<const f32x4*>(hid) + el * FPL + row * FRS + px * 8;
+            f32x4 wk4[9];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            float o8[8];
-            dw_row8(hb + t * 8 * FPL, wks + (t * 8 + el) * 9, o8);
-            float2 sp[5];
-            rfft8_row(o8, sp);
+            for (int i = 0; i < 9; ++i) wk4[i] = reinterpret_cast<const f32x4*>(wks)[el * 9 + i];
+            fdn_f32x2 aqk[8], avv[8];
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * KXS + row] = sp[kx];
+            for (int j = 0; j < 8; ++j) aqk[j] = fdn_f32x2{0.f, 0.f}, avv[j] = fdn_f32x2{0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                f32x4 v[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) v[j] = hc[dy * FRS + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {                            // (each sum in the order of dw_row8: same bits)
+                        aqk[j] = __builtin_elementwise_fma(wk4[dy * 3 + dx].xy, v[j + dx].xy, aqk[j]);
+                        avv[j] = __builtin_elementwise_fma(wk4[dy * 3 + dx].zw, v[j + dx].zw, avv[j]);
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float o8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] = t == 0 ? aqk[j].x : t == 1 ? aqk[j].y : avv[j].x;
+                float2 sp[5];
+                rfft8_row(o8, sp);
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * KXS + row] = sp[kx];
+            }
+            float vv8[8];                                                      // v_value: no transform, straight out
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vv8[j] = avv[j].y;
+            st_store8<OBF>(vv8, rout, e < E ? opix + (unsigned)(3 * E + e) * hwo : OOB, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float o8[8];
+                dw_row8(hb + t * 8 * FPL, wks + (t * 8 + el) * 9, o8);
+                float2 sp[5];
+                rfft8_row(o8, sp);
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * KXS + row] = sp[kx];
+            }
         }
         __syncthreads();
 
@@ -767,7 +823,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                 S[(1 * NP + pj) * PS + kx * KXS + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
                 S[(2 * NP + pj) * PS + kx * KXS + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
             }
-        } else if (wave == 3) {
+        } else if (!CELLS && wave == 3) {
             // the 160 column jobs fill waves 0-2: wave 3, idle otherwise, runs the whole chunk's v_value path meanwhile (depthwise
             // conv of the fourth kind straight to global: no transform) - four (channel, patch, row) jobs per lane
 #pragma unroll 1
@@ -799,20 +855,22 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
 // v_mfma_f32_32x32x16_bf16: slot 3 ks + part = the part-th bf16 part of w[row][16 ks + 8 kh + j] * gamma, j = 0..7; the last
 // slot carries the three parts of the bias row (W beta, fp64 sum) on k = 0, 1, 2 of the lower lane half
 __global__ void fdsa_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 fdn_u32x4* __restrict__ wpk, int C, int E, int nchunks) {
+                                 fdn_u32x4* __restrict__ wpk, int C, int E, int nchunks, int channel_major) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int KST = (C + 15) / 16, KS = KST * 3 + 1;
     if (idx >= nchunks * KS * 64) return;
     const int lane = idx & 63, j = (idx >> 6) % KS, ch = (idx >> 6) / KS;
     const int m = lane & 31, kh = lane >> 5;
-    const int e = ch * FEG + (m & 7);
+    // MFMA row m of a chunk: kind * 8 + channel (fdn_fdsa_full), or channel * 4 + kind (fdn_fdsa_fused: an accumulator register quad is one
+    // (q, k, v, v_value) cell)
+    const int e = ch * FEG + (channel_major ? m >> 2 : m & 7), kind = channel_major ? m & 3 : m >> 3;
     auto part_of = [](float x, int part) {
         for (int p = 0; p < part; ++p) x -= __uint_as_float(__float_as_uint(x) & 0xffff0000u);
         return __float_as_uint(x) >> 16;
     };
     fdn_u32x4 o = {0u, 0u, 0u, 0u};
     if (e < E) {
-        const float* wr = w + (long)((m >> 3) * E + e) * C;
+        const float* wr = w + (long)(kind * E + e) * C;
         if (j < KS - 1) {
             const int ks = j / 3, part = j - 3 * ks;
 #pragma unroll
@@ -903,15 +961,15 @@ extern "C" int fdn_fdffn_mid(const void* x_, const float* w0, const float* w2, c
 }
 
 // the operand image for nch8 >= ceil(E / 8) chunks of 8 channels (chunks past E are zeros): fdn_fdsa_full walks 16-channel chunks at C > 32
-int fdn_fdsa_pack_chunks(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, int nch8, hipStream_t s) {
+int fdn_fdsa_pack_chunks(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, int nch8, hipStream_t s, int channel_major) {
     FDN_CHECK_ARG(w && wpk && C > 0 && C % 2 == 0 && E > 0 && (!gamma == !beta) && nch8 * FEG >= E);
     const int total = nch8 * (((C + 15) / 16) * 3 + 1) * 64;
-    hipLaunchKernelGGL(fdsa_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, gamma, beta, reinterpret_cast<fdn_u32x4*>(wpk), C, E, nch8);
+    hipLaunchKernelGGL(fdsa_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, gamma, beta, reinterpret_cast<fdn_u32x4*>(wpk), C, E, nch8, channel_major);
     return fdn_launch_status();
 }
 
 extern "C" int fdn_fdsa_pack(const float* w, const float* gamma, const float* beta, float* wpk, int C, int E, fdn_stream_t stream) {
-    return fdn_fdsa_pack_chunks(w, gamma, beta, wpk, C, E, (E + FEG - 1) / FEG, static_cast<hipStream_t>(stream));
+    return fdn_fdsa_pack_chunks(w, gamma, beta, wpk, C, E, (E + FEG - 1) / FEG, static_cast<hipStream_t>(stream), 1);
 }
 
 extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
