@@ -330,8 +330,9 @@ def ffn_tail(y, dw_w, w, res=None, want_stats=False, mode=None, cache=None):
     if mode is None:
         # measured on MI355X (tools/bench_kernels.py tail, B = 8 720p): one launch wins for the 32-wide outputs (level 1: FDFFN 86 -> 32
         # 1.60 vs 1.94 ms, FCAFFN 32 -> 32 0.75 vs 0.97 ms) and for the 64 -> 64 FCAFFN tail of level 2 (0.56 vs 0.76 ms); the deep
-        # 172 -> 64 FDFFN tail of level 2 (1.24 vs 1.06 ms) and everything at level 3 stay on gate + GEMM
-        mode = "sw" if (W % 4 == 0 and (N <= 32 or (N <= 64 and C <= 64))) else "split"
+        # 172 -> 64 FDFFN tail of level 2 lost in round 3 (1.24 vs 1.06 ms) and wins since the packed (A, B) stencil of round 4 (1.01-1.08
+        # vs 1.05-1.11 ms; the Fuse shape 172 -> 64 at 736 x 1280: 3.70 vs 4.18 ms, tools/tail_modes.py); level 3 (N = 128) stays on gate + GEMM
+        mode = "sw" if (W % 4 == 0 and N <= 64) else "split"
     if mode == "split":
         g = dwconv_gate(y, dw_w)                 # (bf16 storage in -> bf16 storage out -> the project_out conv reads bf16)
         return conv1x1(g, w, res=res, want_stats=want_stats, cache=cache)
