@@ -268,6 +268,9 @@ template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as 
 #ifndef FDN_MID_WGS
 #define FDN_MID_WGS 3
 #endif
+#ifndef FDN_MID_CONV2_LATE
+#define FDN_MID_CONV2_LATE 1
+#endif
 __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                            const float* __restrict__ w2, const float* __restrict__ ffta,
                                                            const float* __restrict__ fftp, float* __restrict__ out, int Hd,
@@ -453,8 +456,7 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 
         // ---- B: tin is free: park the prefetched halo; second conv; column transforms --------------
         if (more) stash();
-        float sp[8];
-        {
+        auto second_conv = [&](float (&sp)[8]) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sp[j] = 0.f;
 #pragma unroll
@@ -467,7 +469,11 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) sp[j] = fmaf(k2[dy * 3 + dx], v[j + dx], sp[j]);
             }
-        }
+        };
+#if FDN_MID_CONV2_LATE == 0
+        float sp[8];
+        second_conv(sp);
+#endif
         // columns: forward, z * ffta * e^{-i fftp}, inverse  (FDN_arch.py:460-469)
         if (tid < NP * 5) {
             const int pj = tid / 5, kx = tid - pj * 5;
@@ -492,6 +498,10 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
             for (int kx = 0; kx < 5; ++kx) xk[kx] = S[patch * PS + kx * KXS + rr];
             float r[8];
             irfft8_row(xk, r);
+#if FDN_MID_CONV2_LATE
+            float sp[8];
+            second_conv(sp);
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] += sp[j];                                                              // :470
             st_store8<OBF>(r, rout, ooff, (unsigned)c * hwo);
