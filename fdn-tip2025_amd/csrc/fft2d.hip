@@ -866,10 +866,16 @@ template <int R, int P> struct ColPlan {
     static constexpr size_t lds = ((size_t)R * KS + (size_t)(P - 1) * R) * sizeof(float2);
 };
 
+#ifndef FDN_COLS_NB3
+#define FDN_COLS_NB3 16
+#endif
+#ifndef FDN_COLS_WGS3
+#define FDN_COLS_WGS3 1
+#endif
 template <int R, int P, int MODE>
 // (two workgroups per CU: the FCAFFN mode takes 256 registers because of its out-of-line full-range sincos path - the hot path has
 //  no scratch access; capped at 168 registers for three workgroups the hot path spills and runs 0.99 against 0.78 ms, tools/ab_cols_pitch.py)
-__global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
+__global__ __launch_bounds__((ColPlan<R, P>::NT), (FDN_COLS_WGS3 && 3 * ColPlan<R, P>::lds <= 160 * 1024) ? 3 : 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
     constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = ColPlan<R, P>::KS, NJ = R * NG, NT = ColPlan<R, P>::NT;
     static_assert(TC / CJ == NG, "8 column groups");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_cols[];
@@ -923,7 +929,9 @@ __global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(Col
         binq[cc] = (unsigned)(k1 * Wf + (liveq[cc] ? col0 + cc * NG + cg : Wf - 1));      // neighbouring columns (their 32-byte guidance records share lines)
     }
     const unsigned kstep = (unsigned)(R * Wf);      // bins between k2 and k2 + 1
-    constexpr int NB = 4, BS = 32 / NB;             // guidance records in batches of 8, one batch in flight ahead of the arithmetic
+    // guidance records in batches, one batch in flight ahead of the arithmetic: 8 per batch (96 registers for the two buffers) with two
+    // workgroups per CU, 4 per batch (48) where the LDS leaves room for a third workgroup
+    constexpr int NB = (FDN_COLS_WGS3 && 3 * ColPlan<R, P>::lds <= 160 * 1024) ? FDN_COLS_NB3 : 4, BS = 32 / NB;
     fdn_u32x4 g0[2][BS];
     fdn_u32x2 g1[2][BS];
     __amdgpu_buffer_rsrc_t rg = rz;
@@ -1007,10 +1015,27 @@ __global__ __launch_bounds__((ColPlan<R, P>::NT), 2) void fft_cols_rp_kernel(Col
         }
         if (MODE == COL_FCAFFN) {
             if (__builtin_expect(modulate(std::false_type{}), 0)) {
+                // (round 4) the redo is a ROLLED loop over the thread's own LDS cells: inlined 32 times, the full-range sincos took the whole
+                // kernel to 256 registers (two workgroups per CU); like this the cold path needs fewer registers than the hot one
                 asm volatile("" ::: "memory");      // start over from memory: nothing of the first pass is kept alive for this one
                 forward();                          // Y still holds the step-2 values of this thread's cells
-                gload(std::integral_constant<int, 0>{});
-                modulate(std::true_type{});
+                sfor<0, 32>([&](auto qq) { constexpr int q = decltype(qq)::value; yb[(q % P) * TC + (q / P) * NG] = v[q]; });
+#pragma unroll 1
+                for (int q = 0; q < 32; ++q) {
+                    const int cc = q / P, n = q % P, k2 = (int)(__brev((unsigned)n) >> (P == 32 ? 27 : P == 16 ? 28 : 29));
+                    unsigned bq = binq[0];
+#pragma unroll
+                    for (int j = 1; j < CJ; ++j) bq = cc == j ? binq[j] : bq;
+                    const fdn_u32x4 ga = __builtin_amdgcn_raw_buffer_load_b128(rg, bq * 32u, (unsigned)k2 * kstep * 32u, 0);
+                    const fdn_u32x2 gp = __builtin_amdgcn_raw_buffer_load_b64(rg, bq * 32u, (unsigned)k2 * kstep * 32u + 16u, 0);
+                    const float A_ = wa0 * __uint_as_float(ga.x) + wa1 * __uint_as_float(ga.y) + wa2 * __uint_as_float(ga.z);
+                    const float ph = wp0 * __uint_as_float(ga.w) + wp1 * __uint_as_float(gp.x) + wp2 * __uint_as_float(gp.y);
+                    float sn, cs;
+                    fdn_sincos<true>(ph, &sn, &cs);
+                    const f2 x = yb[n * TC + cc * NG];
+                    yb[n * TC + cc * NG] = fftr::cmul(f2{rd1(x.x), rd1(x.y)}, f2{A_ * cs, -A_ * sn});
+                }
+                sfor<0, 32>([&](auto qq) { constexpr int q = decltype(qq)::value; v[q] = yb[(q % P) * TC + (q / P) * NG]; });
             }
         }
         if (MODE == COL_INV_POLAR) {
