@@ -873,8 +873,9 @@ template <int R, int P> struct ColPlan {
 #define FDN_COLS_WGS3 1
 #endif
 template <int R, int P, int MODE>
-// (two workgroups per CU: the FCAFFN mode takes 256 registers because of its out-of-line full-range sincos path - the hot path has
-//  no scratch access; capped at 168 registers for three workgroups the hot path spills and runs 0.99 against 0.78 ms, tools/ab_cols_pitch.py)
+// (three workgroups per CU where the LDS allows it, R <= 23.  Round 3 ran the FCAFFN mode at two: inlined 32 times, its full-range sincos
+//  redo took 256 registers, and capped at 168 the hot path spilled - 0.99 against 0.78 ms.  Round 4: the redo is a rolled loop over the
+//  thread's LDS cells and the guidance records come in batches of 2 instead of 8: 168 registers, no scratch, 9.34 -> 8.22 ms per step)
 __global__ __launch_bounds__((ColPlan<R, P>::NT), (FDN_COLS_WGS3 && 3 * ColPlan<R, P>::lds <= 160 * 1024) ? 3 : 2) void fft_cols_rp_kernel(ColArgs a, const float2* __restrict__ twT) {
     constexpr int H = R * P, TC = 256 / P, CJ = 32 / P, NG = 8, KS = ColPlan<R, P>::KS, NJ = R * NG, NT = ColPlan<R, P>::NT;
     static_assert(TC / CJ == NG, "8 column groups");

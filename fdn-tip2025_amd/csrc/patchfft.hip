@@ -668,8 +668,9 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         if (tid < 64) fgs[tid + 256] = st_f1;
     };
     // (C >= 48: the strips alone take 108 / 144 registers, so the A operands are not held in registers at all - each k-step reads its
-    //  three fragments from L1 / L2 - and no instantiation spills: 1.43 ms against 1.53-1.56 ms at level 2 for the variants that hold
-    //  them in registers and spill 14-18, tools/ab_libs.py)
+    //  three fragments from L1 / L2: 1.43 ms against 1.53-1.56 ms at level 2 for the variants that hold them in registers.  C = 64 STILL
+    //  spills 20 registers - loop-invariant coordinates stored once and reloaded by ~12 scratch loads per chunk, profiles/r04_spills.txt;
+    //  C <= 48 does not spill)
     // ---- to_hidden of one chunk on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes (0 outside the image: the
     // strip, its statistics and `xone` all read 0 there)
     auto mfma_phase = [&](int ch) __attribute__((always_inline)) {
