@@ -1300,8 +1300,11 @@ __global__ __launch_bounds__(256, 2) void rfft_rows_rp_kernel(const float* __res
             const long row = row0 + rwc, plane = row / lnp.H;
             const int h = (int)(row - plane * lnp.H), c = (int)(plane % lnp.C);
             const long b = plane / lnp.C, HW = (long)lnp.H * W;
-            const __amdgpu_buffer_rsrc_t rs_ = cols_rsrc(lnp.stats + b * 2 * HW, 2 * HW * 4);
-            const unsigned so = (unsigned)(h * W + 2 * n2) * 4u;
+            // ONE descriptor over the whole statistics tensor, the batch item in the per-lane offset: the rows of a workgroup may belong to two
+            // batch items, so a descriptor per item is a per-lane value and every load behind it sits in a waterfall loop (40-60 per thread,
+            // tools/isa_waterfall.py).  (The host refuses tensors past 2^31 bytes.)
+            const __amdgpu_buffer_rsrc_t rs_ = cols_rsrc(lnp.stats, (R / ((long)lnp.C * lnp.H)) * 2 * HW * 4);
+            const unsigned so = (unsigned)(b * 2 * HW + h * W + 2 * n2) * 4u;
             const float ga = lnp.gamma[c], be = lnp.beta[c];
             f2 mu[R1], rs[R1];
             sfor<0, R1>([&](auto n1) {
@@ -1635,6 +1638,7 @@ extern "C" int fdn_rfft_rows_ln(const float* x, const float* stats, const float*
     int R1 = 0, P = 0;
     if (!rows_plan(W, &R1, &P) || (reinterpret_cast<uintptr_t>(x) & 7) != 0 || (reinterpret_cast<uintptr_t>(stats) & 7) != 0)
         return FDN_ERR_UNSUPPORTED;                           // widths with a compile-time plan only: else fdn_layernorm_chan + fdn_rfft_rows
+    if ((long)B * 2 * H * W * 4 > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;      // the statistics of all batch items sit behind one 2 GB descriptor
     const RowLN ln = {stats, gamma, beta, C, H};
     const long rows = (long)B * C * H;
 #define FDN_CALL(a, b) launch_rfft_rp<a, b>(x, out_c, rows, stream, pitch, &ln)

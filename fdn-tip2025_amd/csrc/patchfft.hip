@@ -283,8 +283,11 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
     const int tid = threadIdx.x;
     const int ngroups = (Hd + CPB - 1) / CPB;
     const unsigned item = xcd_contiguous(blockIdx.x, gridDim.x);           // (b, channel group, tile), tile fastest
-    const int tile = item % ntiles, cbase = ((item / ntiles) % ngroups) * CPB, b = item / (ntiles * ngroups);
-    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+    // (the run-time divisions go through the vector ALU: without the readfirstlanes the plane offsets below count as per-lane values and
+    //  every halo load of the channel loop sits in a waterfall loop - 12 of them, ~150 issue slots per channel; tools/isa_waterfall.py)
+    const int tile = __builtin_amdgcn_readfirstlane((int)(item % ntiles)), cbase = __builtin_amdgcn_readfirstlane((int)((item / ntiles) % ngroups) * CPB),
+              b = __builtin_amdgcn_readfirstlane((int)(item / (ntiles * ngroups)));
+    const int ty0 = __builtin_amdgcn_readfirstlane((tile / tiles_x) * TH), tx0 = __builtin_amdgcn_readfirstlane((tile % tiles_x) * TW);
     constexpr unsigned IES = st_bytes<IBF>(), OES = st_bytes<OBF>();
     const unsigned hw4 = (unsigned)H * W * IES;                 // bytes per input plane; Hd planes per image < 4 GB (checked by the host)
     const unsigned hwo = (unsigned)H * W * OES;
@@ -328,13 +331,16 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
         }
     }
     auto fetch = [&](int c) {
-        if (V4) { halo_v4_fetch(rin, (unsigned)c * hw4, hv, hd); return; }
+        // (the plane offset must reach the loads in a scalar register: the compiler keeps the strength-reduced c * hw4 of the channel loop in a
+        //  VECTOR register and then wraps every load in a waterfall loop - 12 per channel, tools/isa_waterfall.py)
+        const unsigned po = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)c * hw4));
+        if (V4) { halo_v4_fetch(rin, po, hv, hd); return; }
         if constexpr (IBF) {
 #pragma unroll
-            for (int i = 0; i < HPP; ++i) prep[i] = __builtin_amdgcn_raw_buffer_load_b32(rin, goffp[i], (unsigned)c * hw4, 0);
+            for (int i = 0; i < HPP; ++i) prep[i] = __builtin_amdgcn_raw_buffer_load_b32(rin, goffp[i], po, 0);
         } else {
 #pragma unroll
-            for (int i = 0; i < HPT2; ++i) pre[i] = st_load1<IBF>(rin, goff[i], (unsigned)c * hw4);
+            for (int i = 0; i < HPT2; ++i) pre[i] = st_load1<IBF>(rin, goff[i], po);
         }
     };
     auto stash = [&]() {
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] += sp[j];                                                              // :470
-            st_store8<OBF>(r, rout, ooff, (unsigned)c * hwo);
+            st_store8<OBF>(r, rout, ooff, (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)c * hwo)));
         }
         __syncthreads();                                          // S, mid, filt are rewritten by the next channel
     }
