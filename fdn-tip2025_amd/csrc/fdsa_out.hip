@@ -239,6 +239,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
     f32x2 vv[SH], oa[SH], ob2[DB ? SH : 1];
     bool fetched = false;                                     // DB: v_value and group 0 of this tile were requested by the previous tile
     for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        // The plane offsets 2 s PI / n P4 below are loop invariants: hoisted out of this persistent loop they are ~100 live scalars, and the
+        // compiler parked them in vector-register lanes - 249 v_writelane + 307 v_readlane + 375 wait states in the 76-channel form.  Opaque
+        // per-trip copies of the two strides keep each offset one s_mul beside its use.
+        unsigned PIl = PI, P4l = P4;
+        asm volatile("" : "+s"(PIl), "+s"(P4l));
+        // (the same for the channel-range predicates 2 s + kh < E / n + 4 kh < N: hoisted, each is a 64-bit lane mask - 140 scalar registers)
+        int khl = kh;
+        asm volatile("" : "+v"(khl));
         const int b = tile_b(tile);
         const unsigned p_ = tile_p(tile, b);
         const bool ok = p_ < P;                               // P % 2 == 0: a pixel pair is inside or outside as a whole
@@ -253,8 +261,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
         } else {
 #pragma unroll
             for (int s = 0; s < SH; ++s) {
-                vv[s] = oload2<IBF>(rv, voff, (unsigned)(2 * s) * PI);
-                oa[s] = oload2<IBF>(rg[0], voff, (unsigned)(2 * s) * PI);
+                vv[s] = oload2<IBF>(rv, voff, (unsigned)(2 * s) * PIl);
+                oa[s] = oload2<IBF>(rg[0], voff, (unsigned)(2 * s) * PIl);
             }
         }
         const unsigned nb4 = (unsigned)N * P4;
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             if (DB && g < 2) {
                 f32x2* nxt = (g & 1) ? oa : ob2;
 #pragma unroll
-                for (int s = 0; s < SH; ++s) nxt[s] = oload2<IBF>(rg[g + 1], voff, (unsigned)(2 * s) * PI);
+                for (int s = 0; s < SH; ++s) nxt[s] = oload2<IBF>(rg[g + 1], voff, (unsigned)(2 * s) * PIl);
             }
             // LayerNorm statistics of this group from registers (two-pass; lanes l and l^32 split the channels)
             f32x2 m = 0.f;
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
 #pragma unroll
             for (int s = 0; s < SH; ++s) {
                 const f32x2 dl = cur[s] - m;
-                q += (2 * s + kh < E) ? dl * dl : f32x2(0.f);
+                q += (2 * s + khl < E) ? dl * dl : f32x2(0.f);
             }
             f32x2 rs;
             rs.x = 1.0f / sqrtf((q.x + __shfl_xor(q.x, 32)) * invE + 1e-5f);
@@ -313,8 +321,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
                     const rsrc_t nrv = oplanes(nb, 3), nr0 = oplanes(nb, 0);
 #pragma unroll
                     for (int s = 0; s < SH; ++s) {
-                        vv[s] = oload2<IBF>(nrv, nvoff, (unsigned)(2 * s) * PI);
-                        ob2[s] = oload2<IBF>(nr0, nvoff, (unsigned)(2 * s) * PI);
+                        vv[s] = oload2<IBF>(nrv, nvoff, (unsigned)(2 * s) * PIl);
+                        ob2[s] = oload2<IBF>(nr0, nvoff, (unsigned)(2 * s) * PIl);
                     }
                 }
             }
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        rres[mt][r] = bload2(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4);      // 0 without a residual
+                        rres[mt][r] = bload2(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4l);      // 0 without a residual
             }
 #pragma unroll
             for (int s = 0; s < SH; ++s) {
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             }
             if (!DB && g < 2) {
 #pragma unroll
-                for (int s = 0; s < SH; ++s) oa[s] = oload2<IBF>(rg[g + 1], voff, (unsigned)(2 * s) * PI);
+                for (int s = 0; s < SH; ++s) oa[s] = oload2<IBF>(rg[g + 1], voff, (unsigned)(2 * s) * PIl);
             }
         }
         // ---- epilogue: residual (one batch), store, next LayerNorm's statistics -------------------------------------
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    rres[mt][r] = bload2(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4);      // 0 without a residual
+                    rres[mt][r] = bload2(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4l);      // 0 without a residual
         }
         f32x2 sm = 0.f;
 #pragma unroll
@@ -357,8 +365,8 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int nrow = mt * 32 + (r & 3) + 8 * (r >> 2);
                 f32x2 o = f32x2{acc[mt][0][r], acc[mt][1][r]} + rres[mt][r];
-                bstore2(o, ro, vo, (unsigned)nrow * P4);
-                outv[mt][r] = (nrow + 4 * kh < N) ? o : f32x2(0.f);
+                bstore2(o, ro, vo, (unsigned)nrow * P4l);
+                outv[mt][r] = (nrow + 4 * khl < N) ? o : f32x2(0.f);
                 sm += outv[mt][r];
             }
         if (a.stats_out) {
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fdsa_out_vec_kernel(FoArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const f32x2 dl = outv[mt][r] - mean;
-                    sq += (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < N) ? dl * dl : f32x2(0.f);
+                    sq += (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khl < N) ? dl * dl : f32x2(0.f);
                 }
             rstd.x = 1.0f / sqrtf((sq.x + __shfl_xor(sq.x, 32)) / (float)N + 1e-5f);
             rstd.y = 1.0f / sqrtf((sq.y + __shfl_xor(sq.y, 32)) / (float)N + 1e-5f);
