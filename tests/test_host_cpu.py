@@ -183,3 +183,21 @@ def test_ratio_sweep_grid_and_names_follow_the_reference():
     assert len(vals) == 100 and all(float(a) == float(b) for a, b in zip(vals, ref))
     assert [M.output_name(v) for v in vals[:3]] == ["{}.png".format(i) for i in ref[:3]] == ["0.0.png", "0.01.png", "0.02.png"]
     assert M.output_name(vals[29]) == "{}.png".format(ref[29])
+
+
+def test_no_waterfall_loops_in_the_patch_kernels(tmp_path):
+    """The compiler wrapped every halo load of fdffn_mid's channel loop in a waterfall loop (the strength-reduced plane offset lived in a vector
+    register: 12 loops, ~150 issue slots per channel).  Compile patchfft.hip to gfx950 assembly and hold the count at 0."""
+    import importlib.util
+    import subprocess
+    root = ROOT
+    out = tmp_path / "patchfft.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only", "-S",
+                    os.path.join(root, "fdn-tip2025_amd", "csrc", "patchfft.hip"), "-o", str(out)], check=True, timeout=600)
+    spec = importlib.util.spec_from_file_location("isa_waterfall", os.path.join(root, "tools", "isa_waterfall.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stats = mod.waterfalls(str(out))
+    kernels = [k for k in stats if "fdffn_mid_kernel" in k or "fdsa_fused_kernel" in k or "fdsa_core_kernel" in k]
+    assert len(kernels) >= 10, sorted(stats)
+    assert {k: stats[k][0] for k in kernels if stats[k][0]} == {}
