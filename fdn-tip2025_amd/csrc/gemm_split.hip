@@ -497,6 +497,124 @@ __global__ __launch_bounds__(256, 2) void gemm_split_strip_kernel(SArgs a) {
     }
 }
 
+// (round 4) The same kernel with the weight tiles travelling global -> LDS directly (buffer_load_dwordx4 ... lds: no staging registers,
+// no ds_write) and TWO accumulators: tile t + 1's MFMA chain runs while tile t's 16 stores are issued between its MFMAs.  Knock-outs of the
+// form above (tools/ab_gemm_l3.py, 128 -> 612: 0.43 ms as shipped, 0.28 without its stores, 0.34 without barrier + stash, 0.20 without
+// both = the MFMA time) showed its waves marching in step: chain, stores and barrier added up instead of overlapping.
+template <int NKS, int PRO>
+__global__ __launch_bounds__(256, 2) void gemm_split_strip2_kernel(SArgs a, unsigned wbytes) {
+    const fdn_conv1x1_desc& d = a.d;
+    constexpr int UNITS = 3 * NKS * 2 * 32;              // 16-byte units of one 32-channel weight tile
+    static_assert(UNITS % 256 == 0, "whole waves of 16-byte lanes");
+    constexpr int PER = UNITS / 256;
+    // (two arrays, not one [2][UNITS]: the compiler orders every LDS read behind ALL outstanding direct-to-LDS loads it cannot prove disjoint -
+    //  with a run-time buffer index that is a vmcnt(0) in front of each tile's first operand read, i.e. no prefetch and a wait for the stores)
+    __shared__ __attribute__((aligned(16))) fdn_u32x4 Ws0[UNITS];
+    __shared__ __attribute__((aligned(16))) fdn_u32x4 Ws1[UNITS];
+    __shared__ __attribute__((aligned(16))) float bs[STRIP_MAX_N];
+    const int K = d.K, N = d.N;
+    const unsigned P = (unsigned)d.P, P4 = P * 4u;
+    const int tid = threadIdx.x, lane = tid & 63, kh = lane >> 5, ln = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nch = (K + KC - 1) / KC;
+    const unsigned S = xcd_contiguous(blockIdx.x, (unsigned)a.total_ptiles);
+    const int b = (int)(S / (unsigned)a.tiles_per_img);
+    const unsigned p0 = (S - (unsigned)b * a.tiles_per_img) * TP;
+    const unsigned p = p0 + (unsigned)(wave * 32 + ln), pix = min(p, P - 1);
+    const rsrc_t rx = mk_rsrc(d.x[0] + (long)b * d.xbs[0], (unsigned)K * P4);
+    const rsrc_t rw = mk_rsrc(static_cast<const float*>(d.wpk), wbytes);
+
+    // weight tile t -> LDS buffer t & 1, unit u = tid + 256 i (layout as in gemm_split_strip_kernel): lane-contiguous 16-byte cells, so a
+    // wave's 64 units are one direct-to-LDS load
+    auto dma = [&](int t, fdn_u32x4* Wd) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int u = tid + 256 * i;
+            const int n = u & 31, h = (u >> 5) & 1, q = u >> 6, ks8 = q % NKS, part = q / NKS;
+            const int src = ((((t >> 2) * nch + (ks8 >> 1)) * 3 + part) * 2 + (ks8 & 1)) * 256 + h * 128 + (t & 3) * 32 + n;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(&Wd[256 * i + 64 * wave]), 16, src * 16, 0, 0, 0);
+        }
+    };
+    dma(0, Ws0);
+
+    fdn_u32x4 Bf[NKS][3];
+    {
+        float sa = 1.f, sb = 0.f;
+        if (PRO == FDN_PRO_LN) {
+            const float* sp = d.stats + (long)b * 2 * P;
+            sa = sp[P + pix];
+            sb = -sp[pix] * sa;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = bload(rx, pix * 4u + (unsigned)(kh * 8) * P4, (unsigned)(ks * 16 + j) * P4);     // k >= K reads 0
+            if (PRO == FDN_PRO_LN) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], sa, sb);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned p1, p2, p3;
+                fdn_split3(v[2 * j], v[2 * j + 1], p1, p2, p3);
+                Bf[ks][0][j] = p1, Bf[ks][1][j] = p2, Bf[ks][2][j] = p3;
+            }
+        }
+    }
+    for (int i = tid; i < STRIP_MAX_N; i += 256) bs[i] = (d.bias && i < N) ? d.bias[i] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const rsrc_t ro = mk_rsrc(d.out + (long)b * d.obs, (unsigned)N * P4);
+    const unsigned voff = p < P ? (4u * kh * P + p) * 4u : 0x80000000u;
+    const int ntl = (N + 31) / 32;
+    f32x16 acc[2];
+    // tile t into acc[cur] while the 16 stores of tile t - 1 (acc[cur ^ 1]) go out, two behind every k-step's six MFMAs
+    auto tile = [&](int t, const fdn_u32x4* Wc, fdn_u32x4* Wn, f32x16& cur, const f32x16& prev, bool has_prev) __attribute__((always_inline)) {
+        if (t + 1 < ntl) dma(t + 1, Wn);
+        const fdn_u32x4* wb = Wc + kh * 32 + ln;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(&bs[t * 32 + 8 * g + 4 * kh]);
+            cur[4 * g] = bv.x, cur[4 * g + 1] = bv.y, cur[4 * g + 2] = bv.z, cur[4 * g + 3] = bv.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const fdn_u32x4 a1 = wb[((0 * NKS + ks) * 2) * 32], a2 = wb[((1 * NKS + ks) * 2) * 32], a3 = wb[((2 * NKS + ks) * 2) * 32];
+            cur = mf(a3, Bf[ks][0], cur);
+            cur = mf(a2, Bf[ks][1], cur);
+            cur = mf(a1, Bf[ks][2], cur);
+            cur = mf(a2, Bf[ks][0], cur);
+            cur = mf(a1, Bf[ks][1], cur);
+            cur = mf(a1, Bf[ks][0], cur);
+            if (has_prev) {
+#pragma unroll
+                for (int r = (16 * ks) / NKS; r < (16 * (ks + 1)) / NKS; ++r)
+                    bstore(prev[r], ro, voff, (unsigned)((t - 1) * 32 + (r & 3) + 8 * (r >> 2)) * P4);      // rows >= N fall outside the descriptor
+            }
+            __builtin_amdgcn_sched_barrier(0);                // the stores stay between the k-steps
+        }
+        // the direct-to-LDS loads of tile t + 1 are older than the stores just issued: in-order completion, so "at most 16 outstanding" covers them
+        if (has_prev) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    tile(0, Ws0, Ws1, acc[0], acc[1], false);
+    int t = 1;
+    for (; t + 1 < ntl; t += 2) {
+        tile(t, Ws1, Ws0, acc[1], acc[0], true);
+        tile(t + 1, Ws0, Ws1, acc[0], acc[1], true);
+    }
+    if (t < ntl) {
+        tile(t, Ws1, Ws0, acc[1], acc[0], true);
+        ++t;
+    }
+    const f32x16& last = (ntl & 1) ? acc[0] : acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bstore(last[r], ro, voff, (unsigned)((ntl - 1) * 32 + (r & 3) + 8 * (r >> 2)) * P4);
+}
+
 template <int NKS, int PRO>
 int launch_strip(const fdn_conv1x1_desc& d, hipStream_t s) {
     SArgs a = {};
@@ -504,6 +622,16 @@ int launch_strip(const fdn_conv1x1_desc& d, hipStream_t s) {
     a.tiles_per_img = cdiv(d.P, TP);
     a.total_ptiles = d.B * a.tiles_per_img;
     a.ntiles = 1;
+#ifndef FDN_STRIP2
+#define FDN_STRIP2 1
+#endif
+    if constexpr (FDN_STRIP2 && (3 * NKS * 2 * 32) % 256 == 0 && NKS >= 6) {
+        const long wbytes = (long)cdiv(d.N, TN) * ((d.K + KC - 1) / KC) * BLK * 16;      // = fdn_conv1x1_pack_bytes(N, K, 0)
+        if (wbytes < 0x7FFFFFFFL) {
+            hipLaunchKernelGGL((gemm_split_strip2_kernel<NKS, PRO>), dim3((unsigned)a.total_ptiles), dim3(256), 0, s, a, (unsigned)wbytes);
+            return fdn_launch_status();
+        }
+    }
     hipLaunchKernelGGL((gemm_split_strip_kernel<NKS, PRO>), dim3((unsigned)a.total_ptiles), dim3(256), 0, s, a);
     return fdn_launch_status();
 }
