@@ -445,6 +445,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries ONE line, the JSON record of rank 0: everything else a rank or a library writes to file descriptor 1 (RCCL prints a version
+    # banner through C stdio, flushed at exit - i.e. BEHIND a line printed earlier) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != a.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {a.gpus}: the two must agree")
 
@@ -649,7 +654,8 @@ def main():
                                            "note": "the same K steps with every rank's shard already resident (no scatter / gather)"}
         if a.dry_run:
             line["dry_run"] = True
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if dist is not None:
         dist.destroy_process_group()
 
