@@ -151,7 +151,6 @@ __global__ __launch_bounds__(256) void dw_gate_kernel(const float* __restrict__ 
         // 16-byte lanes for the 64 interior columns of the halo rows (W % 4 == 0, planes 16-byte aligned: a float4 is inside
         // or outside the image as a whole), dword loads only for the two edge columns: 4 load instructions per plane
         // instead of 9, and a wave touches 1 KB contiguous
-        typedef float f4 __attribute__((ext_vector_type(4)));
         constexpr int NV = (TH + 2) * 16;                   // 544 float4 of the interior
         float qa[3][4], qb[3][4], qc[3][4];
         int qs[3];
