@@ -154,6 +154,32 @@ def test_fdn_end_to_end_tamed(A, name):
         assert p > floor, f"{name}.{key}: PSNR {p:.1f} dB (reference self-noise: see tests/golden/selfnoise.json)"
 
 
+def _window_rms(d, size):
+    B, C, H, W = d.shape
+    return d.double().pow(2).reshape(B, C, H // size, size, W // size, size).mean((1, 3, 5)).sqrt().reshape(-1)
+
+
+@pytest.mark.parametrize("name", ["fdn_tamed_64", "fdn_tamed_96x160"])
+def test_fdn_end_to_end_tamed_conditioning(A, name):
+    """The same forwards held per WINDOW to what fp32 can do there (the footing of test_config1_736x1280_frame_matches_reference): against the
+    float64 truth a window may be off by 4 x the worst of the reference's own error and the measured fp32 susceptibility of THAT window
+    (tests/golden/make_golden_small_cond.py: five fp32 oracle evaluations, eight float64 evaluations with emulated FFT rounding), plus a few
+    ulp.  The 96 x 160 frame has one ill-conditioned spot (windows 16, 17, 26, 27 of y: 1e-6 .. 6e-5 under rounding-sized noise, 3e-8 elsewhere):
+    a fixed PSNR floor there tests the luck of one rounding, this test the arithmetic."""
+    fx, cond = fixture(name), fixture(name + "_cond")
+    m = load(A.FDN(), fdn_weights(tame=float(fx["tame"])))
+    with torch.no_grad():
+        out = m(dev(fx["x"]), ratio_i=dev(fx["ratio"]), device=torch.device("cuda:0"))
+    for got, key, size in zip(out, ("y", "q1", "q2", "q3"), (16, 16, 8, 4)):
+        truth = cond[key + "_f64"]
+        e_hip, e_ref = _window_rms(got.cpu().double() - truth, size), _window_rms(fx[key].double() - truth, size)
+        susc = torch.maximum(cond[key + "_susc"].max(0).values, cond[key + "_noise"].max(0).values)
+        allow = 4.0 * torch.maximum(e_ref, susc) + 5e-8
+        bad = (e_hip > allow).nonzero().flatten().tolist()
+        assert not bad, f"{name}.{key}: windows {bad[:8]}: HIP {e_hip[bad[:8]].tolist()} allowed {allow[bad[:8]].tolist()}"
+        assert float(e_hip.median()) <= 2.0 * float(e_ref.median()) + 2e-8, (name, key, float(e_hip.median()), float(e_ref.median()))
+
+
 def test_harness_u8(A):
     """uint8 in -> uint8 out through the drop-in modules, mirroring inference_fdn_lolblur.py:47-75."""
     from basicsr.models.archs.LPNet_arch import I_predict_net
