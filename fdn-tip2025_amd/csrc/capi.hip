@@ -6,12 +6,15 @@ extern "C" int fdn_abi_version(void) { return 10; }
 
 // Diagnostic switch: 1 = every matrix product of the path on the fp32 MFMA (the round-2 kernels) instead of the
 // split-bf16 forms on v_mfma_f32_32x32x16_bf16, so that the cross-stream finding can be bisected.  Process-wide, default 0.
-static std::atomic<int> g_matrix_pipe_f32{0};
-extern "C" int fdn_set_matrix_pipe(int fp32_only) {
-    g_matrix_pipe_f32.store(fp32_only ? 1 : 0);
+// 2 (round 4) = the bf16 pipe ALSO for the level-2 FDSA tail (fdn_fdsa_out, E in 39..76): built and 16 % faster, not the default - see fdsa_out.hip.
+static std::atomic<int> g_matrix_pipe_mode{0};
+extern "C" int fdn_set_matrix_pipe(int mode) {
+    if (mode < 0 || mode > 2) return FDN_ERR_ARG;
+    g_matrix_pipe_mode.store(mode);
     return FDN_OK;
 }
-bool fdn_matrix_pipe_f32() { return g_matrix_pipe_f32.load() != 0; }
+bool fdn_matrix_pipe_f32() { return g_matrix_pipe_mode.load() == 1; }
+bool fdn_matrix_pipe_wide() { return g_matrix_pipe_mode.load() == 2; }
 
 extern "C" const char* fdn_error_string(int code) {
     switch (code) {

@@ -103,16 +103,22 @@ _matrix_pipe = "bf16"
 
 def set_matrix_pipe(name):
     """"bf16" (default): matrix products as six bf16 products of exactly split fp32 operands on v_mfma_f32_32x32x16_bf16;
-    "f32": the fp32-MFMA forms only (diagnostic: bisecting the cross-stream finding of DESIGN.md 4.7; same results to rounding)."""
+    "f32": the fp32-MFMA forms only (diagnostic: bisecting the cross-stream finding of DESIGN.md 4.7; same results to rounding);
+    "bf16-wide": "bf16" plus the level-2 FDSA tail on the bf16 pipe (built in round 4, faster, not the default yet: DESIGN.md section 8)."""
     global _matrix_pipe
-    if name not in ("bf16", "f32"):
-        raise ValueError(f"matrix pipe must be 'bf16' or 'f32', got {name!r}")
-    check(lib().fdn_set_matrix_pipe(int(name == "f32")), "fdn_set_matrix_pipe")
+    if name not in ("bf16", "f32", "bf16-wide"):
+        raise ValueError(f"matrix pipe must be 'bf16', 'f32' or 'bf16-wide', got {name!r}")
+    check(lib().fdn_set_matrix_pipe({"bf16": 0, "f32": 1, "bf16-wide": 2}[name]), "fdn_set_matrix_pipe")
     _matrix_pipe = name
 
 
 def matrix_pipe():
-    return _matrix_pipe
+    """"bf16" or "f32" ("bf16-wide" - the bf16 pipe also for the level-2 FDSA tail, not the default: include/fdn_hip.h - reports as "bf16")."""
+    return "bf16" if _matrix_pipe == "bf16-wide" else _matrix_pipe
+
+
+def matrix_pipe_wide():
+    return _matrix_pipe == "bf16-wide"
 
 
 def dev(t, what="tensor"):

@@ -39,11 +39,14 @@ enum { FDN_RS_BILINEAR_HALF = 0, FDN_RS_BILINEAR_X2 = 1, FDN_RS_NEAREST_HALF = 2
 /* library version / build info: returns the ABI version (bumped on any signature change) */
 int fdn_abi_version(void);
 const char* fdn_error_string(int code);
-/* Diagnostic switch, process-wide, default 0.  fp32_only = 1: no kernel that issues v_mfma_f32_32x32x16_bf16 is launched - the
+/* Diagnostic switch, process-wide, default 0.  mode = 1: no kernel that issues v_mfma_f32_32x32x16_bf16 is launched - the
  * 1x1 / 3x3 convs run their fp32-MFMA forms, fdn_fdsa_fused / fdn_fdsa_full / fdn_fcaffn_in_packed return FDN_ERR_UNSUPPORTED (the
  * host mirror then takes the unfused launches).  Exists so that the cross-stream finding of DESIGN.md 4.7 can be bisected;
- * same results to fp32 rounding, slower.  (No reference counterpart.) */
-int fdn_set_matrix_pipe(int fp32_only);
+ * same results to fp32 rounding, slower.  mode = 2 (round 4): the bf16 pipe also for the level-2 FDSA tail (fdn_fdsa_out with
+ * E in 39..76: one pixel per lane, packed operands in LDS; 0.71 against 0.84 ms, fp32-grade like every split-bf16 product here) -
+ * not the default until the small end-to-end fixture is understood.  Other values: FDN_ERR_ARG.
+ * (No reference counterpart.) */
+int fdn_set_matrix_pipe(int mode);
 
 /* ------------------------------------------------------------------------------------------
  * 1x1 convolution as fp32-MFMA GEMM with fused prologue / epilogue.

@@ -154,6 +154,42 @@ def test_fdn_end_to_end_tamed(A, name):
         assert p > floor, f"{name}.{key}: PSNR {p:.1f} dB (reference self-noise: see tests/golden/selfnoise.json)"
 
 
+@pytest.mark.parametrize("B,E,N,H,W", [(2, 76, 64, 48, 80), (1, 76, 64, 40, 36), (1, 57, 48, 16, 12), (2, 76, 64, 184, 320)])
+def test_fdsa_out_level2_on_the_bf16_pipe(B, E, N, H, W):
+    """fdn_set_matrix_pipe(2): the level-2 FDSA tail (three LayerNorms * v_value, project_out, residual, statistics; FDN_arch.py:633-639, :671)
+    with project_out on v_mfma_f32_32x32x16_bf16 - one pixel per lane, eight waves around one packed operand image.  Against float64 it has to
+    be as good as the default fp32-MFMA form (a ragged last tile, E < 2 * SH and N < 64 included); the switch goes back to the default afterwards."""
+    import ctypes
+    import fdn_hip
+    P = H * W
+    g = torch.Generator().manual_seed(11)
+    o, w = torch.randn(B, 4 * E, P, generator=g), torch.randn(N, 3 * E, generator=g) / (3 * E) ** .5
+    g3, b3, res = torch.randn(3 * E, generator=g), torch.randn(3 * E, generator=g), torch.randn(B, N, P, generator=g)
+    od, v = o.double(), o.double()[:, 3 * E:]
+    parts = []
+    for k in range(3):
+        og = od[:, k * E:(k + 1) * E]
+        mu, var = og.mean(1, keepdim=True), og.var(1, unbiased=False, keepdim=True)
+        parts.append(((og - mu) / torch.sqrt(var + 1e-5) * g3[k * E:(k + 1) * E].double()[None, :, None] + b3[k * E:(k + 1) * E].double()[None, :, None]) * v)
+    ref = torch.einsum("nk,bkp->bnp", w.double(), torch.cat(parts, 1)) + res.double()
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    errs = {}
+    try:
+        for mode in ("bf16", "bf16-wide"):
+            fdn_hip.set_matrix_pipe(mode)
+            od_, wd, gd, bd, rd = dev(o), dev(w), dev(g3), dev(b3), dev(res)
+            out = torch.full((B, N, P), float("nan"), device="cuda:0")
+            st = torch.full((B, 2, P), float("nan"), device="cuda:0")
+            rc = fdn_hip.lib().fdn_fdsa_out(ptr(od_), ptr(wd), ptr(gd), ptr(bd), ptr(rd), ptr(out), ptr(st), B, E, N, P, 0, fdn_hip.stream())
+            assert rc == 0
+            torch.cuda.synchronize()
+            errs[mode] = rel_rms(out.cpu(), ref)
+            assert rel_rms(st[:, 0].cpu(), ref.mean(1)) < 1e-5 and rel_rms(st[:, 1].cpu(), 1 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5)) < 1e-5, mode
+    finally:
+        fdn_hip.set_matrix_pipe("bf16")
+    assert errs["bf16-wide"] < 2e-6 and errs["bf16-wide"] < 1.5 * errs["bf16"] + 2e-8, errs
+
+
 def _window_rms(d, size):
     B, C, H, W = d.shape
     return d.double().pow(2).reshape(B, C, H // size, size, W // size, size).mean((1, 3, 5)).sqrt().reshape(-1)
