@@ -431,6 +431,8 @@ def main():
     ap.add_argument("--eager", dest="graph", action="store_false", help="issue every launch from Python instead of replaying the captured graph")
     ap.add_argument("--config", choices=("fdn", "lpnet"), default="fdn",
                     help="fdn = LPNet -> FDN (the metric); lpnet = I_predict_net alone on the same batch (BASELINE.json configs[4] / SURVEY 8d C5)")
+    ap.add_argument("--wide-pipe", action="store_true", help="A/B: fdn_set_matrix_pipe(2) - the level-2 FDSA tail on the bf16 matrix pipe too (built in round 4, "
+                    "fp32-grade, not the default: DESIGN.md section 8)")
     ap.add_argument("--fdsa-full", action="store_true", help="A/B: route the level-1 FDSA sub-blocks through fdn_fdsa_full (one launch) instead of "
                     "fdn_fdsa_fused + fdn_fdsa_out (DESIGN.md section 4: built, correct, not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -492,6 +494,8 @@ def main():
         import fdn_hip
         fdn_hip.set_storage_dtype(a.dtype)
         fdn_hip.ops.FDSA_FULL = bool(a.fdsa_full)
+        if a.wide_pipe:
+            fdn_hip.set_matrix_pipe("bf16-wide")
         net, lp = build_models(dev, a.variant)
         x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
         mk = lambda r: make_input(a.batch, a.height, a.width, dev, seed=1000 + r)
@@ -633,7 +637,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                        "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full),
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "wide_pipe": bool(a.wide_pipe),
                        "host_issue_ms_per_step": host_issue_ms, "cpu_affinity_rank0": affinity},
             # B_alg = 7,256 elements per padded pixel x sizeof(elem) - 4 bytes in fp32, 2 in the bf16-storage configuration
             "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * (ips / world) / (PEAK_HBM_GBS * 1e9),
