@@ -2,6 +2,11 @@
 modules named *_arch.py in this directory are importable by class name."""
 import importlib
 import os
+from pkgutil import extend_path
+
+# other *_arch.py modules (mar_arch, ...) still import from a reference checkout later on sys.path; FDN_arch, LPNet_arch and
+# fdnlol24_arch are found here first
+__path__ = extend_path(__path__, __name__)
 
 _arch_dir = os.path.dirname(os.path.abspath(__file__))
 _arch_files = sorted(f[:-3] for f in os.listdir(_arch_dir) if f.endswith("_arch.py"))

@@ -201,3 +201,44 @@ def test_no_waterfall_loops_in_the_patch_kernels(tmp_path):
     kernels = [k for k in stats if "fdffn_mid_kernel" in k or "fdsa_fused_kernel" in k or "fdsa_core_kernel" in k]
     assert len(kernels) >= 10, sorted(stats)
     assert {k: stats[k][0] for k in kernels if stats[k][0]} == {}
+
+
+def test_reference_driver_imports_through_the_shadow(tmp_path):
+    """this package FIRST on PYTHONPATH, a reference checkout after it.  The checkout here is a stub laid out like the
+    reference (basicsr/ WITHOUT an __init__.py, basicsr/utils/__init__.py with the four helpers, basicsr/models/__init__.py that must NOT run,
+    a reference-only arch module); the import lines are those of /root/reference/inference_fdn_lolblur.py:1-6, executed verbatim in a fresh
+    interpreter.  FDN / I_predict_net must come from this package, the helpers from the checkout."""
+    import subprocess
+    import sys
+    ck = tmp_path / "checkout"
+    (ck / "basicsr" / "utils").mkdir(parents=True)
+    (ck / "basicsr" / "models" / "archs").mkdir(parents=True)
+    (ck / "basicsr" / "utils" / "__init__.py").write_text(
+        "def get_root_logger(*a, **k): return 'logger'\ndef imwrite(*a, **k): return 'imwrite'\n"
+        "def tensor2img(*a, **k): return 'tensor2img'\ndef img2tensor(*a, **k): return 'img2tensor'\ndef scandir(*a, **k): return []\n")
+    (ck / "basicsr" / "models" / "__init__.py").write_text("raise RuntimeError('the training stack of the checkout must not be imported')\n")
+    (ck / "basicsr" / "models" / "archs" / "__init__.py").write_text("raise RuntimeError('the registry of the checkout must not be imported')\n")
+    (ck / "basicsr" / "models" / "archs" / "FDN_arch.py").write_text("raise RuntimeError('shadowing failed: the reference FDN_arch was imported')\n")
+    (ck / "basicsr" / "models" / "archs" / "mar_arch.py").write_text("MAR_ONLY_IN_CHECKOUT = 1\n")
+    driver_lines = (
+        "from basicsr.utils import get_root_logger, imwrite, tensor2img\n"
+        "\n"
+        "from basicsr.models.archs.FDN_arch import *\n"
+        "\n"
+        "from basicsr.models.archs.LPNet_arch import *\n"
+        "from basicsr.utils import img2tensor\n")
+    check = (
+        "import basicsr, os\n"
+        "pkg = os.environ['FDN_PKG']\n"
+        "assert FDN.__module__ == 'basicsr.models.archs.FDN_arch' and os.path.realpath(sys.modules[FDN.__module__].__file__).startswith(pkg), sys.modules[FDN.__module__].__file__\n"
+        "assert os.path.realpath(sys.modules[I_predict_net.__module__].__file__).startswith(pkg)\n"
+        "assert transforms is not None and F is torch.nn.functional and rearrange is not None and np is not None and nn is torch.nn\n"
+        "assert get_root_logger() == 'logger' and imwrite() == 'imwrite' and tensor2img() == 'tensor2img' and img2tensor() == 'img2tensor'\n"
+        "from basicsr.models.archs.fdnlol24_arch import FDN_lolv1\n"
+        "from basicsr.models.archs import mar_arch, define_network\n"
+        "assert mar_arch.MAR_ONLY_IN_CHECKOUT == 1\n"
+        "assert type(define_network({'type': 'FDN'})).__name__ == 'FDN'\n"
+        "print('shadow ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([entry.PKG, str(ck)]), FDN_PKG=os.path.realpath(entry.PKG))
+    r = subprocess.run([sys.executable, "-c", "import sys\n" + driver_lines + check], env=env, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "shadow ok" in r.stdout, r.stderr[-2000:]
