@@ -72,94 +72,152 @@ def _iv(v):
     return v.value if hasattr(v, "value") else v
 
 
+class _Call:
+    """The arguments of one C-ABI call BY NAME (fdn_hip/_abi.py ARG_NAMES, generated from include/fdn_hip.h): a reordered or inserted
+    parameter of a later ABI version cannot silently shift a shape figure - a missing name raises KeyError instead."""
+
+    def __init__(self, name, args):
+        from fdn_hip._abi import ARG_NAMES
+        names = ARG_NAMES[name]
+        if len(names) != len(args):
+            raise TypeError(f"{name}: {len(args)} arguments against {len(names)} declared in include/fdn_hip.h")
+        self._kw = dict(zip(names, args))
+
+    def i(self, *keys):
+        """the named integer arguments as Python ints (one value for one key, a tuple otherwise)"""
+        vals = tuple(int(_iv(self._kw[k])) for k in keys)
+        return vals[0] if len(vals) == 1 else vals
+
+    def given(self, key):
+        """a pointer argument that may be NULL: True when it is set"""
+        v = self._kw[key]
+        return v is not None and bool(_iv(v))
+
+    def obj(self, key):
+        return self._kw[key]
+
+
+def _describe_conv1x1(c):
+    d = c.obj("d")._obj
+    f = 2.0 * d.B * d.K * d.N * d.P
+    b = d.B * d.P * ((2.0 if d.x_bf16 else 4.0) * d.K + (2.0 if d.out_bf16 else 4.0) * d.N
+                     + 4.0 * ((d.N if d.epi == 1 else 0) + (2 * d.N if d.epi == 2 else 0)
+                              + (d.K // 3 if d.pro == 2 else 0) + (d.K if d.pro == 3 else 0)))
+    return f"fdn_conv1x1[{d.K}->{d.N},pro{d.pro},epi{d.epi},P={d.P}{',xbf16' if d.x_bf16 else ''}{',obf16' if d.out_bf16 else ''}]", f, b
+
+
+def _describe_fdsa_fused(c):
+    B, C, E, H, W = c.i("B", "C", "E", "H", "W")
+    ob = 2.0 if c.i("out_bf16") else 4.0
+    return f"fdn_fdsa_fused[C={C},E={E},{H}x{W}{',obf16' if ob == 2.0 else ''}]", 2.0 * B * H * W * C * 4 * E, B * H * W * (4.0 * C + ob * 4 * E)
+
+
+def _describe_fdsa_full(c):
+    B, C, E, H, W = c.i("B", "C", "E", "H", "W")
+    return f"fdn_fdsa_full[C={C},E={E},{H}x{W}]", 2.0 * B * H * W * (C * 4 * E + 3 * E * C), 4.0 * B * H * W * (3 * C + 2)
+
+
+def _describe_fdsa_core(c):
+    B, E, H, W = c.i("B", "E", "H", "W")
+    return f"fdn_fdsa_core[E={E},{H}x{W}]", 0.0, 4.0 * B * H * W * 8 * E
+
+
+def _describe_fdsa_out(c):
+    B, E, N, P = c.i("B", "E", "N", "P")
+    ib = 2.0 if c.i("o_bf16") else 4.0
+    return f"fdn_fdsa_out[E={E},N={N},P={P}{',ibf16' if ib == 2.0 else ''}]", 2.0 * B * P * 3 * E * N, B * P * (ib * 4 * E + 4.0 * 2 * N)
+
+
+def _describe_fdffn_mid(c):
+    B, Hd, H, W = c.i("B", "Hd", "H", "W")
+    ib, ob = (2.0 if c.i("x_bf16") else 4.0), (2.0 if c.i("out_bf16") else 4.0)
+    return f"fdn_fdffn_mid[Hd={Hd},{H}x{W}{',bf16' if ib + ob < 8 else ''}]", 0.0, B * H * W * Hd * (ib + ob)
+
+
+def _describe_dwconv_gate(c):
+    B, C, H, W = c.i("B", "C", "H", "W")
+    ib, ob = (2.0 if c.i("x_bf16") else 4.0), (2.0 if c.i("out_bf16") else 4.0)
+    return f"fdn_dwconv_gate[C={C},{H}x{W}{',bf16' if ib + ob < 8 else ''}]", 0.0, B * H * W * C * (ib + ob)
+
+
+def _describe_ffn_tail(c):
+    B, C, N, H, W = c.i("B", "C", "N", "H", "W")
+    ib = 2.0 if c.i("y_bf16") else 4.0
+    return (f"fdn_ffn_tail[{C}->{N},{H}x{W},form{c.i('form')}{',ibf16' if ib == 2.0 else ''}]", 2.0 * B * H * W * C * N,
+            B * H * W * (ib * C + 4.0 * 2 * N))
+
+
+def _describe_rfft_rows(c):
+    rows, W = c.i("rows", "W")
+    return f"fdn_rfft_rows[W={W},rows={rows}]", 0.0, 4.0 * rows * (W + 2 * (W // 2 + 1))
+
+
+def _describe_irfft_rows(c):
+    planes, H, W = c.i("planes", "H", "W")
+    return f"fdn_irfft_rows[{H}x{W},planes={planes}]", 0.0, 4.0 * planes * H * (2 * (W // 2 + 1) + W + (W if c.given("res") else 0))
+
+
+def _describe_fft_cols_fcaffn(c):
+    B, C, H, Wf = c.i("B", "C", "H", "Wf")
+    return f"fdn_fft_cols_fcaffn[C={C},{H}x{Wf}]", 0.0, 4.0 * B * H * Wf * (4 * C + 8)
+
+
+def _describe_rfft_rows_ln(c):
+    B, C, H, W = c.i("B", "C", "H", "W")
+    return f"fdn_rfft_rows_ln[W={W},rows={B * C * H}]", 0.0, 4.0 * B * H * (C * (W + 2 * (W // 2 + 1)) + 2 * W)
+
+
+def _describe_fcaffn_in(c):
+    B, C, H, W = c.i("B", "C", "H", "W")
+    return f"fdn_fcaffn_in[C={C},{H}x{W}]", 2.0 * B * H * W * C * (C + 2 * 27), 4.0 * B * H * W * (3 * C + 3)
+
+
+def _describe_fcaffn_in_packed(c):
+    B, C, H, W = c.i("B", "C", "H", "W")
+    return f"fdn_fcaffn_in_packed[C={C},{H}x{W}]", 2.0 * B * H * W * C * (C + 2 * 27), 4.0 * B * H * W * (3 * C + 3 + 4)   # xi, x1, out, the image, two statistics pairs
+
+
+def _describe_conv2d(c):
+    B, Cin, H, W, Cout, KH, KW, st, pad = c.i("B", "Cin", "H", "W", "Cout", "KH", "KW", "stride", "pad")
+    OH, OW = (H + 2 * pad - KH) // st + 1, (W + 2 * pad - KW) // st + 1
+    return (f"fdn_conv2d[{Cin}->{Cout},k{KH}s{st},{H}x{W}]", 2.0 * B * OH * OW * Cin * Cout * KH * KW,
+            4.0 * B * (Cin * H * W + Cout * OH * OW * (2 if c.given("res") else 1)))
+
+
+def _describe_chan_stats(c):
+    B, G, E, P = c.i("B", "G", "E", "P")
+    return f"fdn_chan_stats[G={G},E={E},P={P}]", 0.0, 4.0 * B * P * (G * E + 2 * G)
+
+
+def _describe_layernorm_chan(c):
+    B, C, P = c.i("B", "C", "P")
+    return f"fdn_layernorm_chan[C={C},P={P}]", 0.0, 4.0 * B * P * 2 * C
+
+
+def _describe_img_mod_maps(c):
+    B, C, H, W = c.i("B", "C", "H", "W")
+    return f"fdn_img_mod_maps[C={C},{H}x{W}]", 0.0, 4.0 * B * H * W * (3 + 2 * C)
+
+
+# entry point -> parser of its call.  tests/test_host_cpu.py feeds every parser a call built from the header's own prototype and checks that
+# the key carries the values under their NAMES; entry points without a parser are grouped under their bare name with no roofline figure.
+DESCRIBERS = {
+    "fdn_conv1x1": _describe_conv1x1, "fdn_fdsa_fused": _describe_fdsa_fused, "fdn_fdsa_full": _describe_fdsa_full,
+    "fdn_fdsa_core": _describe_fdsa_core, "fdn_fdsa_out": _describe_fdsa_out, "fdn_fdffn_mid": _describe_fdffn_mid,
+    "fdn_dwconv_gate": _describe_dwconv_gate, "fdn_ffn_tail": _describe_ffn_tail, "fdn_rfft_rows": _describe_rfft_rows,
+    "fdn_irfft_rows": _describe_irfft_rows, "fdn_fft_cols_fcaffn": _describe_fft_cols_fcaffn, "fdn_rfft_rows_ln": _describe_rfft_rows_ln,
+    "fdn_fcaffn_in": _describe_fcaffn_in, "fdn_fcaffn_in_packed": _describe_fcaffn_in_packed, "fdn_conv2d": _describe_conv2d,
+    "fdn_chan_stats": _describe_chan_stats, "fdn_layernorm_chan": _describe_layernorm_chan, "fdn_img_mod_maps": _describe_img_mod_maps,
+}
+
+
 def describe_call(name, a):
-    """(group key, algorithmic FLOPs, algorithmic HBM bytes) of one C-ABI call: the figures of DESIGN.md section 4 (each
-    operand read once, each result written once, fp32), conv FLOPs only (FFT / pointwise work is not counted)."""
-    f = b = 0.0
-    key = name
-    if name == "fdn_conv1x1":
-        d = a[0]._obj
-        f = 2.0 * d.B * d.K * d.N * d.P
-        b = d.B * d.P * ((2.0 if d.x_bf16 else 4.0) * d.K + (2.0 if d.out_bf16 else 4.0) * d.N
-                         + 4.0 * ((d.N if d.epi == 1 else 0) + (2 * d.N if d.epi == 2 else 0)
-                                  + (d.K // 3 if d.pro == 2 else 0) + (d.K if d.pro == 3 else 0)))
-        key = f"fdn_conv1x1[{d.K}->{d.N},pro{d.pro},epi{d.epi},P={d.P}{',xbf16' if d.x_bf16 else ''}{',obf16' if d.out_bf16 else ''}]"
-    elif name == "fdn_fdsa_fused":
-        B, C, E, H, W = (_iv(v) for v in a[7:12])
-        ob = 2.0 if _iv(a[12]) else 4.0
-        f, b = 2.0 * B * H * W * C * 4 * E, B * H * W * (4.0 * C + ob * 4 * E)
-        key = f"fdn_fdsa_fused[C={C},E={E},{H}x{W}{',obf16' if ob == 2.0 else ''}]"
-    elif name == "fdn_fdsa_full":
-        B, C, E, H, W = (_iv(v) for v in a[9:14])
-        f, b = 2.0 * B * H * W * (C * 4 * E + 3 * E * C), 4.0 * B * H * W * (3 * C + 2)
-        key = f"fdn_fdsa_full[C={C},E={E},{H}x{W}]"
-    elif name == "fdn_fdsa_core":
-        B, E, H, W = (_iv(v) for v in a[4:8])
-        b = 4.0 * B * H * W * 8 * E
-        key = f"fdn_fdsa_core[E={E},{H}x{W}]"
-    elif name == "fdn_fdsa_out":
-        B, E, N, P = (_iv(v) for v in a[7:11])
-        ib = 2.0 if _iv(a[11]) else 4.0
-        f, b = 2.0 * B * P * 3 * E * N, B * P * (ib * 4 * E + 4.0 * 2 * N)
-        key = f"fdn_fdsa_out[E={E},N={N},P={P}{',ibf16' if ib == 2.0 else ''}]"
-    elif name == "fdn_fdffn_mid":
-        B, Hd, H, W = (_iv(v) for v in a[6:10])
-        ib, ob = (2.0 if _iv(a[10]) else 4.0), (2.0 if _iv(a[11]) else 4.0)
-        b = B * H * W * Hd * (ib + ob)
-        key = f"fdn_fdffn_mid[Hd={Hd},{H}x{W}{',bf16' if ib + ob < 8 else ''}]"
-    elif name == "fdn_dwconv_gate":
-        B, C, H, W = (_iv(v) for v in a[3:7])
-        ib, ob = (2.0 if _iv(a[7]) else 4.0), (2.0 if _iv(a[8]) else 4.0)
-        b = B * H * W * C * (ib + ob)
-        key = f"fdn_dwconv_gate[C={C},{H}x{W}{',bf16' if ib + ob < 8 else ''}]"
-    elif name == "fdn_ffn_tail":
-        B, C, N, H, W = (_iv(v) for v in a[6:11])
-        ib = 2.0 if _iv(a[11]) else 4.0
-        f, b = 2.0 * B * H * W * C * N, B * H * W * (ib * C + 4.0 * 2 * N)
-        key = f"fdn_ffn_tail[{C}->{N},{H}x{W},form{_iv(a[12])}{',ibf16' if ib == 2.0 else ''}]"
-    elif name == "fdn_rfft_rows":
-        rows, W = _iv(a[2]), _iv(a[3])
-        b = 4.0 * rows * (W + 2 * (W // 2 + 1))
-        key = f"fdn_rfft_rows[W={W},rows={rows}]"
-    elif name == "fdn_irfft_rows":
-        planes, H, W = _iv(a[4]), _iv(a[5]), _iv(a[6])
-        b = 4.0 * planes * H * (2 * (W // 2 + 1) + W + (W if a[8] is not None and _iv(a[8]) else 0))
-        key = f"fdn_irfft_rows[{H}x{W},planes={planes}]"
-    elif name == "fdn_fft_cols_fcaffn":
-        B, C, H, Wf = (_iv(v) for v in a[4:8])
-        b = 4.0 * B * H * Wf * (4 * C + 8)
-        key = f"fdn_fft_cols_fcaffn[C={C},{H}x{Wf}]"
-    elif name == "fdn_rfft_rows_ln":
-        B, C, H, W = (_iv(v) for v in a[5:9])
-        b = 4.0 * B * H * (C * (W + 2 * (W // 2 + 1)) + 2 * W)
-        key = f"fdn_rfft_rows_ln[W={W},rows={B * C * H}]"
-    elif name == "fdn_fcaffn_in":
-        B, C, H, W = (_iv(v) for v in a[14:18])
-        f, b = 2.0 * B * H * W * C * (C + 2 * 27), 4.0 * B * H * W * (3 * C + 3)
-        key = f"fdn_fcaffn_in[C={C},{H}x{W}]"
-    elif name == "fdn_fcaffn_in_packed":
-        B, C, H, W = (_iv(v) for v in a[11:15])
-        f, b = 2.0 * B * H * W * C * (C + 2 * 27), 4.0 * B * H * W * (3 * C + 3 + 4)        # xi, x1, out, the image, two statistics pairs
-        key = f"fdn_fcaffn_in_packed[C={C},{H}x{W}]"
-    elif name == "fdn_conv2d":
-        B, Cin, H, W, Cout, KH, KW, st, pad = (_iv(v) for v in a[5:14])
-        OH, OW = (H + 2 * pad - KH) // st + 1, (W + 2 * pad - KW) // st + 1
-        f = 2.0 * B * OH * OW * Cin * Cout * KH * KW
-        b = 4.0 * B * (Cin * H * W + Cout * OH * OW * (2 if a[3] is not None and _iv(a[3]) else 1))
-        key = f"fdn_conv2d[{Cin}->{Cout},k{KH}s{st},{H}x{W}]"
-    elif name == "fdn_chan_stats":
-        B, G, E, P = (_iv(v) for v in a[3:7])
-        b = 4.0 * B * P * (G * E + 2 * G)
-        key = f"fdn_chan_stats[G={G},E={E},P={P}]"
-    elif name == "fdn_layernorm_chan":
-        B, C, P = (_iv(v) for v in a[4:7])
-        b = 4.0 * B * P * 2 * C
-        key = f"fdn_layernorm_chan[C={C},P={P}]"
-    elif name == "fdn_img_mod_maps":
-        B, C, H, W = (_iv(v) for v in a[7:11])
-        b = 4.0 * B * H * W * (3 + 2 * C)
-        key = f"fdn_img_mod_maps[C={C},{H}x{W}]"
-    return key, f, b
+    """(group key, algorithmic FLOPs, algorithmic HBM bytes) of one C-ABI call: the figures of DESIGN.md (each operand read once, each
+    result written once, fp32 unless a *_bf16 flag is set), conv FLOPs only (FFT / pointwise work is not counted)."""
+    fn = DESCRIBERS.get(name)
+    if fn is None:
+        return name, 0.0, 0.0
+    return fn(_Call(name, a))
 
 
 class KernelTimer:
@@ -328,7 +386,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(h=256, w=256):
+def cpu_baseline(h=256, w=256, full_720p=False):
     """The CPU oracle (fp32, PyTorch CPU ops = a port of the reference's algorithm) on ONE h x w image - BASELINE.json
     configs[0] as it stands - timed the way SURVEY.md 8(d) asks: one warm-up, then the median of three runs, at n = 8 threads
     (comparable with the build container's probe numbers) and at n = all usable host cores.  `value` is the all-cores figure in
@@ -365,6 +423,13 @@ def cpu_baseline(h=256, w=256):
            "by_threads": {str(n): {"images_per_s_config0": 1.0 / statistics.median(v), "seconds": [round(t, 3) for t in v]} for n, v in runs.items()},
            "reference_720p_note": "the reference itself: 0.0028 images/s at 736x1280 on 8 threads in the build container (SURVEY.md 6)",
            "sample": f"1 image {h}x{w} fp32, LPNet+FDN oracle forward, median {dt:.2f} s wall at {cores} threads"}
+    if full_720p:                                                  # ONE real run at the metric's own size, all cores (no warm-up at this size:
+        x = torch.rand(1, 3, 720, 1280, generator=torch.Generator().manual_seed(0))        # the 256 x 256 runs above warmed the libraries)
+        x = torch.nn.functional.pad(x, (0, 0, 0, 16), mode="reflect")
+        torch.set_num_threads(cores)
+        t720 = one()
+        out["measured_736x1280"] = {"images_per_s": 1.0 / t720, "seconds": round(t720, 2), "threads": cores,
+                                    "note": "one timed oracle forward of ONE padded 736x1280 image (no scaling): the CPU figure in the metric's own unit"}
     return out
 
 
@@ -431,8 +496,10 @@ def main():
     ap.add_argument("--eager", dest="graph", action="store_false", help="issue every launch from Python instead of replaying the captured graph")
     ap.add_argument("--config", choices=("fdn", "lpnet"), default="fdn",
                     help="fdn = LPNet -> FDN (the metric); lpnet = I_predict_net alone on the same batch (BASELINE.json configs[4] / SURVEY 8d C5)")
-    ap.add_argument("--wide-pipe", action="store_true", help="A/B: fdn_set_matrix_pipe(2) - the level-2 FDSA tail on the bf16 matrix pipe too (built in round 4, "
-                    "fp32-grade, not the default: DESIGN.md section 8)")
+    ap.add_argument("--narrow-pipe", action="store_true", help="A/B: fdn_set_matrix_pipe(2) - the level-2 FDSA tail on its fp32-MFMA form, the default of ABI 10 "
+                    "(since round 5 the default runs it on the bf16 matrix pipe)")
+    ap.add_argument("--cpu-720p", action="store_true", help="cpu_baseline also times ONE real 736 x 1280 oracle forward (BASELINE.md 4.3 'single timed run at "
+                    "720p': minutes of host time, off by default; the committed line is profiles/r05_cpu_720p.json)")
     ap.add_argument("--fdsa-full", action="store_true", help="A/B: route the level-1 FDSA sub-blocks through fdn_fdsa_full (one launch) instead of "
                     "fdn_fdsa_fused + fdn_fdsa_out (DESIGN.md section 4: built, correct, not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -494,8 +561,8 @@ def main():
         import fdn_hip
         fdn_hip.set_storage_dtype(a.dtype)
         fdn_hip.ops.FDSA_FULL = bool(a.fdsa_full)
-        if a.wide_pipe:
-            fdn_hip.set_matrix_pipe("bf16-wide")
+        if a.narrow_pipe:
+            fdn_hip.set_matrix_pipe("bf16-narrow")
         net, lp = build_models(dev, a.variant)
         x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
         mk = lambda r: make_input(a.batch, a.height, a.width, dev, seed=1000 + r)
@@ -587,7 +654,10 @@ def main():
             cur = kt.summary()
             agg = cur if agg is None else {k: (v if v[2] <= agg.get(k, v)[2] else agg[k]) for k, v in cur.items()}
         total_ms = sum(v[2] for v in agg.values())
-        prof = matching_profile([B, a.height, a.width], a.dtype) if (a.config == "fdn" and a.variant == "lolblur") else None
+        # figures taken from the committed PMC passes describe the DEFAULT routing of the code they were recorded on: with an A/B route
+        # switched on (--fdsa-full, --narrow-pipe) the kernels differ, so nothing is borrowed from them
+        default_routing = not (a.fdsa_full or a.narrow_pipe)
+        prof = matching_profile([B, a.height, a.width], a.dtype) if (a.config == "fdn" and a.variant == "lolblur" and default_routing) else None
         traffic = {k: v["hbm_bytes_per_launch"] for k, v in prof["groups"].items()} if prof else {}
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][2])
         top = []
@@ -608,7 +678,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.dry_run:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(full_720p=a.cpu_720p)
 
     if rank == 0:
         imgs = world * B * a.steps
@@ -637,7 +707,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                        "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "wide_pipe": bool(a.wide_pipe),
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "narrow_pipe": bool(a.narrow_pipe),
                        "host_issue_ms_per_step": host_issue_ms, "cpu_affinity_rank0": affinity},
             # B_alg = 7,256 elements per padded pixel x sizeof(elem) - 4 bytes in fp32, 2 in the bf16-storage configuration
             "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * (ips / world) / (PEAK_HBM_GBS * 1e9),
@@ -647,12 +717,14 @@ def main():
         if a.config == "lpnet":
             line["whole_path"] = None                               # SURVEY 8(d)'s F_alg / B_alg are the LPNet -> FDN path's
         elif prof is not None:
-            # SURVEY 8(d) `roofline.measured`: the bytes the step really moved (committed PMC passes of this shape: memory-side
-            # read requests by size + write requests, one forward of B images) over THIS run's step time, against 8 TB/s
+            # SURVEY 8(d) `roofline.measured`: the bytes a step moves ACCORDING TO THE COMMITTED PMC PASSES of this shape (memory-side read
+            # requests by size + write requests, one forward of B images, recorded on the code of that profile - named in `profile` /
+            # `profile_commit`, NOT measured in this run) over THIS run's step time, against 8 TB/s
             moved = (prof["total"]["read_GB"] + prof["total"]["write_GB"]) * 1e9
-            line["whole_path"].update({"hbm_measured_frac": moved / (dt / a.steps) / (PEAK_HBM_GBS * 1e9), "hbm_measured_GB_per_step": moved / 1e9,
-                                       "hbm_measured_over_algorithmic": moved / (B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * B),
-                                       "hbm_measured_profile": prof["file"]})
+            line["whole_path"].update({"hbm_from_committed_profile_frac": moved / (dt / a.steps) / (PEAK_HBM_GBS * 1e9),
+                                       "hbm_from_committed_profile_GB_per_step": moved / 1e9,
+                                       "hbm_from_committed_profile_over_algorithmic": moved / (B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * B),
+                                       "profile": prof["file"], "profile_commit": prof.get("commit")})
         if dt_nosg is not None:
             line["without_collectives"] = {"value": imgs / dt_nosg, "ms_per_step": dt_nosg / a.steps * 1e3,
                                            "note": "the same K steps with every rank's shard already resident (no scatter / gather)"}

@@ -217,7 +217,7 @@ class TransformerBlock(nn.Module):
             x = self.attn.fused(x, ln=(ops.stats_of(x),) + self.norm1.params(), res=x)
         x = self.ffn.fused(x, ln=(ops.stats_of(x),) + self.norm2.params(), res=x)
         if self.use_light:
-            if (x.shape[1] in ops.FCAFFN_IN_C or (x.shape[1] >= ops.FCAFFN_PACKED_MIN_C and fdn_hip.matrix_pipe() == "bf16")) and x.shape[3] in ops.ROWS_PLANNED_W:      # norm3 on load: no normalised copy of x
+            if (x.shape[1] in ops.FCAFFN_IN_C or (x.shape[1] >= ops.FCAFFN_PACKED_MIN_C and fdn_hip.matrix_pipe() == "bf16")) and ops.rows_ln_ok(x):      # norm3 on load: no normalised copy of x
                 x = self.ffn2.fused(x, x_high, x_p, x_img, res=x, ln=(ops.stats_of(x),) + self.norm3.params())
             else:
                 x = self.ffn2.fused(self.norm3(x), x_high, x_p, x_img, res=x)

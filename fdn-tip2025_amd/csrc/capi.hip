@@ -2,11 +2,11 @@
 #include "common.hpp"
 
 #include <atomic>
-extern "C" int fdn_abi_version(void) { return 10; }
+extern "C" int fdn_abi_version(void) { return 11; }
 
-// Diagnostic switch: 1 = every matrix product of the path on the fp32 MFMA (the round-2 kernels) instead of the
-// split-bf16 forms on v_mfma_f32_32x32x16_bf16, so that the cross-stream finding can be bisected.  Process-wide, default 0.
-// 2 (round 4) = the bf16 pipe ALSO for the level-2 FDSA tail (fdn_fdsa_out, E in 39..76): built and 16 % faster, not the default - see fdsa_out.hip.
+// Diagnostic switch: 1 = every matrix product of the path on the fp32 MFMA (the round-2 kernels) instead of the split-bf16 forms on
+// v_mfma_f32_32x32x16_bf16, so that the cross-stream finding can be bisected.  Process-wide, default 0.
+// 2 = the default of ABI 10: the level-2 FDSA tail (fdn_fdsa_out, E in 39..76) on the fp32 MFMA; since round 5 the default (0) runs it on the bf16 pipe.
 static std::atomic<int> g_matrix_pipe_mode{0};
 extern "C" int fdn_set_matrix_pipe(int mode) {
     if (mode < 0 || mode > 2) return FDN_ERR_ARG;
@@ -14,7 +14,13 @@ extern "C" int fdn_set_matrix_pipe(int mode) {
     return FDN_OK;
 }
 bool fdn_matrix_pipe_f32() { return g_matrix_pipe_mode.load() == 1; }
-bool fdn_matrix_pipe_wide() { return g_matrix_pipe_mode.load() == 2; }
+bool fdn_matrix_pipe_wide() { return g_matrix_pipe_mode.load() == 0; }
+
+// Every host launcher of a kernel that issues v_mfma_f32_32x32x16_bf16 / 32x32x8_bf16 reports here, so that the promise of
+// fdn_set_matrix_pipe(1) ("no bf16-MFMA kernel is launched") is a number a test can read.
+static std::atomic<long long> g_bf16_launches{0};
+void fdn_note_bf16_launch() { g_bf16_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" long fdn_bf16_mfma_launches(void) { return g_bf16_launches.load(); }
 
 extern "C" const char* fdn_error_string(int code) {
     switch (code) {

@@ -23,7 +23,8 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 int fdn_device_cus();
 bool fdn_allow_dynamic_lds(const void* kernel, size_t bytes);
 bool fdn_matrix_pipe_f32();                                   // fdn_set_matrix_pipe(1): no bf16-MFMA kernel is launched
-bool fdn_matrix_pipe_wide();                                  // fdn_set_matrix_pipe(2): the bf16 pipe also where it is not the default yet
+void fdn_note_bf16_launch();                                  // called by every launcher of a bf16-MFMA kernel (fdn_bf16_mfma_launches)
+bool fdn_matrix_pipe_wide();                                  // default mode: fdn_fdsa_out's level-2 shape on the bf16 pipe too (mode 2 = the ABI-10 default keeps it on fp32 MFMAs)
 bool fdn_occupancy(int* blocks_per_cu, const void* kernel, int threads, size_t lds);   // hipOccupancyMaxActiveBlocksPerMultiprocessor, cached
 
 __device__ __forceinline__ float gelu_erf(float x) {

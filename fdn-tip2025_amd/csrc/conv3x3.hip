@@ -361,6 +361,7 @@ int launch_split(const C3Args& a, hipStream_t s) {
     const int tx = cdiv(a.W, TW), ty = cdiv(a.H, TH_);
     const long total = (long)tx * ty * a.B * cdiv(a.Cout, N);
     if (total > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
+    fdn_note_bf16_launch();
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), lds, s, a, tx, ty);
     return fdn_launch_status();
 }
@@ -397,7 +398,9 @@ int fdn_conv3x3_mfma(const float* x, const float* w, const float* bias, const fl
     a.act = act; a.res_before_act = res_before_act; a.post_add = post_add;
     a.tiles_per_img = a.total_tiles = 0;
     a.n0 = 0; a.CoutT = Cout;
-    if (Cin % CK == 0 && Cin >= 2 * CK && Cout >= 16)           // LDS-tiled, both operands as three bf16 parts on the bf16 matrix pipe
+    // fdn_set_matrix_pipe(1) promises that NO bf16-MFMA kernel is launched: the gate lives here, so every caller keeps it (wide outputs then take the
+    // flat fp32-MFMA form below)
+    if (!fdn_matrix_pipe_f32() && Cin % CK == 0 && Cin >= 2 * CK && Cout >= 16)           // LDS-tiled, both operands as three bf16 parts on the bf16 matrix pipe
         return Cout <= 32 ? launch_split<1, 4>(a, s) : launch_split<2, 8>(a, s);      // (8 x 32 tiles, two workgroups per CU / 16 x 32, one)
     const int tiles = (Cout + 31) / 32;
     if (tiles == 1) return launch<1, 4>(a, s);

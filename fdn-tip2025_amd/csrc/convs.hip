@@ -427,7 +427,7 @@ extern "C" int fdn_conv2d(const float* x, const float* w, const float* bias, con
         // goes to the LDS-tiled split-bf16 MFMA form (64->32 @L1 2.3 ms against 5.5 ms direct, 24->24 0.21 against 0.89 ms);
         // the LDS-weight direct kernel keeps the narrow ones (12->12 0.47 ms against 2.0 ms on the flat MFMA form)
         int rc = FDN_ERR_UNSUPPORTED;
-        if (stride == 1 && Cin % 8 == 0 && Cin >= 16 && Cout >= 16 && !fdn_matrix_pipe_f32()) {          // LDS-tiled MFMA form (split-bf16 operands, conv3x3.hip)
+        if (stride == 1 && Cin % 8 == 0 && Cin >= 16 && Cout >= 16 && !fdn_matrix_pipe_f32()) {          // LDS-tiled MFMA form (split-bf16 operands, conv3x3.hip; the f32 gate is repeated inside)
             rc = fdn_conv3x3_mfma(x, w, bias, res, out, B, Cin, H, W, Cout, act, res_before_act, post_add, s);
             if (rc != FDN_ERR_UNSUPPORTED) return rc;
         }

@@ -617,6 +617,7 @@ int launch_full(FullArgs a, int B, hipStream_t s) {
     a.nchunks = (a.E + G::CE - 1) / G::CE;
     const long total = (long)B * a.tiles_per_img;
     if (total > 0x7fffffffL) return FDN_ERR_UNSUPPORTED;
+    fdn_note_bf16_launch();
     if (a.stats) hipLaunchKernelGGL((fdsa_full_kernel<C, PT, true>), dim3((unsigned)total), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((fdsa_full_kernel<C, PT, false>), dim3((unsigned)total), dim3(256), 0, s, a);
     return fdn_launch_status();

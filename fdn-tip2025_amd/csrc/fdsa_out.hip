@@ -468,6 +468,7 @@ int launch_vec(FoArgs a, hipStream_t s) {
     a.total_tiles = a.B * a.tiles_per_img;
     int grid = cus * (NWV == 8 ? 1 : 2);
     if (grid > a.total_tiles) grid = a.total_tiles;
+    if (PBF) fdn_note_bf16_launch();
     hipLaunchKernelGGL((fdsa_out_vec_kernel<SH, MT, DB, IBF, PX, NWV, PBF>), dim3(grid), dim3(NWV * 64), lds, s, a);
     return fdn_launch_status();
 }
@@ -515,8 +516,8 @@ extern "C" int fdn_fdsa_out(const void* o_, const float* w, const float* gamma3,
     }
     if (vec_ok && sh <= 19 && mt == 1) return launch_vec<19, 1, true, false>(a, s);       // level 1, 8-byte lanes
     // level 2.  (round 4) one pixel per lane, eight waves around one packed operand image, project_out on the bf16 matrix pipe - see the note at PxT.
-    // Behind fdn_set_matrix_pipe(2): correct (tests/test_gpu_parity.py) and faster, but a different - equally valid - rounding, and the 96 x 160 end-to-end
-    // fixture has spots where THIS library's evaluations flip under one-ulp changes (tools/windows_small_perturbed.py); not the default until those are understood
+    // The default since round 5 (fdn_set_matrix_pipe(2) keeps the fp32-MFMA form below for A/B runs): as accurate against float64 as that form
+    // (tests/test_gpu_parity.py), a different - equally valid - rounding.
     if (fdn_matrix_pipe_wide() && vec_ok && sh > 19 && sh <= 38 && mt <= 2) return launch_vec<38, 2, false, false, 1, 8, true>(a, s);
     if (vec_ok && sh <= 38 && mt <= 2) return launch_vec<38, 2, false, false>(a, s);
     if (sh <= 19 && mt == 1) return launch<19, 1>(a, s);       // level 1: E = 38, C = 32

@@ -384,6 +384,7 @@ int launch_split(const fdn_conv1x1_desc& d, hipStream_t s) {
     a.tiles_per_img = cdiv(d.P, TP);
     a.total_ptiles = d.B * a.tiles_per_img;
     a.ntiles = cdiv(d.N, TN);
+    fdn_note_bf16_launch();
     hipLaunchKernelGGL(gemm_split_kernel<PRO>, dim3((unsigned)(a.total_ptiles * a.ntiles)), dim3(256), 0, s, a);
     return fdn_launch_status();
 }
@@ -628,10 +629,12 @@ int launch_strip(const fdn_conv1x1_desc& d, hipStream_t s) {
     if constexpr (FDN_STRIP2 && (3 * NKS * 2 * 32) % 256 == 0 && NKS >= 6) {
         const long wbytes = (long)cdiv(d.N, TN) * ((d.K + KC - 1) / KC) * BLK * 16;      // = fdn_conv1x1_pack_bytes(N, K, 0)
         if (wbytes < 0x7FFFFFFFL) {
+            fdn_note_bf16_launch();
             hipLaunchKernelGGL((gemm_split_strip2_kernel<NKS, PRO>), dim3((unsigned)a.total_ptiles), dim3(256), 0, s, a, (unsigned)wbytes);
             return fdn_launch_status();
         }
     }
+    fdn_note_bf16_launch();
     hipLaunchKernelGGL((gemm_split_strip_kernel<NKS, PRO>), dim3((unsigned)a.total_ptiles), dim3(256), 0, s, a);
     return fdn_launch_status();
 }
@@ -766,6 +769,7 @@ extern "C" int fdn_fcaffn_in_packed(const float* xi, const float* stats_xi, cons
     a.tiles_per_img = cdiv((int)P, TP);
     a.total_ptiles = B * a.tiles_per_img;
     a.ntiles = cdiv(C, TN);
+    fdn_note_bf16_launch();
     hipLaunchKernelGGL((gemm_split_kernel<FDN_PRO_LN_MULADD, true>), dim3((unsigned)(a.total_ptiles * a.ntiles)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a);
     return fdn_launch_status();

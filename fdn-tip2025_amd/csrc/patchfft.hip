@@ -1022,5 +1022,6 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
         default: return FDN_ERR_UNSUPPORTED;
     }
 #undef FDN_FUSED_CASE
+    fdn_note_bf16_launch();
     return fdn_launch_status();
 }

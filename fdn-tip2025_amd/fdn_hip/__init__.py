@@ -37,7 +37,7 @@ class FdnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 10         # include/fdn_hip.h: bumped on any signature change
+ABI_VERSION = 11         # include/fdn_hip.h: bumped on any signature change
 
 
 def lib_path():
@@ -103,22 +103,29 @@ _matrix_pipe = "bf16"
 
 def set_matrix_pipe(name):
     """"bf16" (default): matrix products as six bf16 products of exactly split fp32 operands on v_mfma_f32_32x32x16_bf16;
-    "f32": the fp32-MFMA forms only (diagnostic: bisecting the cross-stream finding of DESIGN.md 4.7; same results to rounding);
-    "bf16-wide": "bf16" plus the level-2 FDSA tail on the bf16 pipe (built in round 4, faster, not the default yet: DESIGN.md section 8)."""
+    "f32": the fp32-MFMA forms only (diagnostic: bisecting the cross-stream finding; same results to rounding) - what it
+    promises is checkable: `bf16_mfma_launches()` stands still;
+    "bf16-narrow": the default of ABI 10 - as "bf16" but the level-2 FDSA tail keeps its fp32-MFMA form (kept for A/B runs)."""
     global _matrix_pipe
-    if name not in ("bf16", "f32", "bf16-wide"):
-        raise ValueError(f"matrix pipe must be 'bf16', 'f32' or 'bf16-wide', got {name!r}")
-    check(lib().fdn_set_matrix_pipe({"bf16": 0, "f32": 1, "bf16-wide": 2}[name]), "fdn_set_matrix_pipe")
+    if name not in ("bf16", "f32", "bf16-narrow"):
+        raise ValueError(f"matrix pipe must be 'bf16', 'f32' or 'bf16-narrow', got {name!r}")
+    check(lib().fdn_set_matrix_pipe({"bf16": 0, "f32": 1, "bf16-narrow": 2}[name]), "fdn_set_matrix_pipe")
     _matrix_pipe = name
 
 
 def matrix_pipe():
-    """"bf16" or "f32" ("bf16-wide" - the bf16 pipe also for the level-2 FDSA tail, not the default: include/fdn_hip.h - reports as "bf16")."""
-    return "bf16" if _matrix_pipe == "bf16-wide" else _matrix_pipe
+    """"bf16" or "f32" ("bf16-narrow" reports as "bf16": the routing of the host mirror is the same)."""
+    return "bf16" if _matrix_pipe == "bf16-narrow" else _matrix_pipe
 
 
-def matrix_pipe_wide():
-    return _matrix_pipe == "bf16-wide"
+def matrix_pipe_mode():
+    """the name last given to set_matrix_pipe (part of the capture key of pipeline.GraphedForward / GraphedStep)"""
+    return _matrix_pipe
+
+
+def bf16_mfma_launches():
+    """number of bf16-MFMA kernel launches this process has enqueued (fdn_bf16_mfma_launches, ABI 11)"""
+    return int(lib().fdn_bf16_mfma_launches())
 
 
 def dev(t, what="tensor"):

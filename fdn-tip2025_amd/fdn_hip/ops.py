@@ -435,6 +435,13 @@ def rfft_rows(x, pitch=None):
 ROWS_PLANNED_W = tuple(2 * r * p for r in (20, 30) for p in (32, 16, 8)) + (608, 304)     # widths fdn_rfft_rows_ln has a form for (19 x 16, 19 x 8: LOL-v1 padded)
 
 
+def rows_ln_ok(x):
+    """fdn_rfft_rows_ln has a form for this tensor: a planned width, and the statistics of the whole batch behind one 2 GB descriptor
+    (fft2d.hip; a larger batch takes fdn_layernorm_chan + fdn_rfft_rows, as include/fdn_hip.h says)"""
+    B, _, H, W = x.shape
+    return W in ROWS_PLANNED_W and B * 2 * H * W * 4 <= 0x7FFFFFFF
+
+
 def rfft_rows_ln(x, stats, gamma, beta, pitch=None):
     """rfft along rows of the channel LayerNorm of x [B, C, H, W], normalised on load (fdn_rfft_rows_ln); W in ROWS_PLANNED_W."""
     B, C, H, W = x.shape

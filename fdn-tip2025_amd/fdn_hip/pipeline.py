@@ -34,7 +34,7 @@ def _check_streams(n_streams):
         raise RuntimeError(
             f"fdn_hip: n_streams={n_streams} refused - kernels of different HIP streams that share the GPU with a bf16-MFMA "
             f"kernel return wrong rows on MI355X / ROCm 7.2 (DESIGN.md 4.7).  Use one stream per GPU, or set {MULTISTREAM_ENV}=1 "
-            "for experiments (optionally with FDN_HIP_MATRIX_PIPE=f32, the fp32-MFMA build of the 1x1 convs, to bisect).")
+            "for experiments (to bisect, call fdn_hip.set_matrix_pipe('f32') first: the fp32-MFMA forms of every matrix product).")
 
 
 def _get_streams(device, n):
@@ -69,10 +69,14 @@ def forward_streams(net, lpnet, x, n_streams=1):
 
 
 def weights_signature(*modules):
-    """What a captured graph depends on besides the input shape: the storage mode and every parameter / buffer of the live
-    module trees (count, in-place version counters, addresses)."""
+    """What a captured graph depends on besides the input shape: the storage mode, the routing switches that decide WHICH kernels a
+    forward launches (the matrix-pipe mode, the optional one-launch FDSA route) and every parameter / buffer of the live module trees
+    (count, in-place version counters, addresses).  A captured graph replays the kernels of its capture: after set_matrix_pipe() or a
+    change of ops.FDSA_FULL the key differs and the holder captures again."""
+    from . import matrix_pipe_mode, ops
     ps = [p for m in modules for p in list(m.parameters()) + list(m.buffers())]
-    return (storage_dtype(), len(ps), sum(p._version for p in ps), sum(p.data_ptr() & 0xFFFFFFFF for p in ps))
+    return (storage_dtype(), matrix_pipe_mode(), bool(ops.FDSA_FULL), int(ops.FDSA_FULL_MAX_C),
+            len(ps), sum(p._version for p in ps), sum(p.data_ptr() & 0xFFFFFFFF for p in ps))
 
 
 class GraphedForward:

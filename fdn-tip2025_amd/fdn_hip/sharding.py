@@ -26,10 +26,71 @@ def split_batch(x_all, world):
 
 def scatter_batch(dist, shard_like, root_shards, src=0):
     """Every rank receives its shard of the root's batch.  root_shards: list of `world` tensors on the root, else None.
-    Shards must have equal shapes (pad the global batch to a multiple of the world size)."""
+    Shards must have equal shapes; a global batch that is not a multiple of the world size goes through scatter_uneven / gather_uneven."""
     out = torch.empty_like(shard_like)
     dist.scatter(out, root_shards if dist.get_rank() == src else None, src=src, async_op=False)      # blocking: see sharded_step
     return out
+
+
+def _pad_rows(t, rows):
+    """t with its first dimension padded to `rows` (the padding repeats the last row: finite values, never read back)"""
+    if t.shape[0] == rows:
+        return t.contiguous()
+    if t.shape[0] == 0:
+        return t.new_zeros((rows,) + tuple(t.shape[1:]))
+    return torch.cat([t, t[-1:].expand(rows - t.shape[0], *t.shape[1:])]).contiguous()
+
+
+def scatter_uneven(dist, total, sample_like, x_all=None, src=0):
+    """A global batch whose size is NOT a multiple of the world size: rank r receives items [b[r], b[r+1]) of `shard_bounds(total, world)`.
+    The collective itself moves equal blocks of cap = ceil(total / world) items (the root pads the short shards; RCCL / gloo scatter wants equal
+    shapes), and every rank keeps only its own count - the padding never reaches the forward, so no compute is spent on it and nothing has to be
+    masked out of the result.  sample_like: a tensor with the shape / dtype / device of ONE item batch [1, ...] (only the trailing dimensions are
+    used); x_all: the global batch on the root, None elsewhere.  Returns the local shard (possibly 0 items when total < world)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    b = shard_bounds(total, world)
+    cap = -(-total // world)
+    buf = sample_like.new_empty((cap,) + tuple(sample_like.shape[1:]))
+    shards = None
+    if rank == src:
+        assert x_all is not None and x_all.shape[0] == total, "scatter_uneven: the root holds the whole global batch"
+        shards = [_pad_rows(x_all[b[r]:b[r + 1]], cap) for r in range(world)]
+    dist.scatter(buf, shards, src=src, async_op=False)
+    return buf[:b[rank + 1] - b[rank]]
+
+
+def gather_uneven(dist, out, total, dst=0):
+    """The inverse of scatter_uneven: every rank contributes its b[r+1] - b[r] output items; the root returns the global output [total, ...] in
+    batch order, the other ranks None."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    b = shard_bounds(total, world)
+    cap = -(-total // world)
+    assert out.shape[0] == b[rank + 1] - b[rank], "gather_uneven: the local output must have this rank's item count"
+    bufs = [out.new_empty((cap,) + tuple(out.shape[1:])) for _ in range(world)] if rank == dst else None
+    dist.gather(_pad_rows(out, cap), bufs, dst=dst, async_op=False)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][:b[r + 1] - b[r]] for r in range(world)])
+
+
+def sharded_run(dist, forward, total, sample_like, x_all=None, root=0):
+    """One pass over a global batch of ANY size: scatter_uneven -> forward on the local items -> gather_uneven, strictly serial like
+    sharded_step (blocking collectives on the compute stream's timeline).  `forward` must accept a batch of this rank's item count (it is not
+    called on a rank that received no item; such a rank contributes an empty block shaped by `out_like` = forward's output for one item, which the
+    root learns from its own shard - the root always holds at least one item when total >= 1)."""
+    xin = scatter_uneven(dist, total, sample_like, x_all, src=root)
+    if xin.shape[0]:
+        out = forward(xin)
+        tail = torch.tensor(list(out.shape[1:]), dtype=torch.int64)
+    else:
+        out, tail = None, None
+    # ranks without an item need the output's trailing shape to take part in the gather: the root (which has one) tells them
+    if total < dist.get_world_size():
+        shape = [tail.tolist() if dist.get_rank() == root else None]
+        dist.broadcast_object_list(shape, src=root)
+        if out is None:
+            out = sample_like.new_empty((0,) + tuple(shape[0]))
+    return gather_uneven(dist, out, total, dst=root)
 
 
 def gather_batch(dist, out, root_bufs, dst=0):

@@ -39,14 +39,17 @@ enum { FDN_RS_BILINEAR_HALF = 0, FDN_RS_BILINEAR_X2 = 1, FDN_RS_NEAREST_HALF = 2
 /* library version / build info: returns the ABI version (bumped on any signature change) */
 int fdn_abi_version(void);
 const char* fdn_error_string(int code);
-/* Diagnostic switch, process-wide, default 0.  mode = 1: no kernel that issues v_mfma_f32_32x32x16_bf16 is launched - the
- * 1x1 / 3x3 convs run their fp32-MFMA forms, fdn_fdsa_fused / fdn_fdsa_full / fdn_fcaffn_in_packed return FDN_ERR_UNSUPPORTED (the
- * host mirror then takes the unfused launches).  Exists so that the cross-stream finding of DESIGN.md 4.7 can be bisected;
- * same results to fp32 rounding, slower.  mode = 2 (round 4): the bf16 pipe also for the level-2 FDSA tail (fdn_fdsa_out with
- * E in 39..76: one pixel per lane, packed operands in LDS; 0.71 against 0.84 ms, fp32-grade like every split-bf16 product here) -
- * not the default until the small end-to-end fixture is understood.  Other values: FDN_ERR_ARG.
- * (No reference counterpart.) */
+/* Diagnostic switch, process-wide, default 0 = every matrix product that has a split-bf16 form runs on the bf16 matrix pipe
+ * (fp32 arithmetic: operands cut exactly into three bf16 parts, six products, fp32 accumulation).  mode = 1: no kernel that issues
+ * v_mfma_f32_32x32x16_bf16 / 32x32x8_bf16 is launched - the 1x1 / 3x3 convs and fdn_fdsa_out run their fp32-MFMA forms, fdn_fdsa_fused /
+ * fdn_fdsa_full / fdn_fcaffn_in_packed return FDN_ERR_UNSUPPORTED (the host mirror then takes the unfused launches).  Exists so that the
+ * cross-stream finding of DESIGN.md can be bisected; same results to fp32 rounding, slower.  mode = 2: as 0, except that the level-2 FDSA
+ * tail (fdn_fdsa_out with E in 39..76) keeps its fp32-MFMA form - the default of ABI 10, kept for A/B runs (0.84 against 0.71 ms per launch).
+ * Other values: FDN_ERR_ARG.  (No reference counterpart.) */
 int fdn_set_matrix_pipe(int mode);
+/* ABI 11: number of bf16-MFMA kernel launches this process has enqueued so far (every launcher counts; what mode 1 promises is that
+ * this number stands still).  Diagnostic; no reference counterpart. */
+long fdn_bf16_mfma_launches(void);
 
 /* ------------------------------------------------------------------------------------------
  * 1x1 convolution as fp32-MFMA GEMM with fused prologue / epilogue.

@@ -14,8 +14,10 @@ sense on a frame WITHOUT such spots.  The model that decides "without" is indepe
   * FFT noise     float64 oracle, every forward rfft2 fed t + 2e-7 rms(t) randn (make_golden_small_cond.py);
   * fp32 oracle   the frame and one-ulp perturbations of it.
 score(seed) = the largest per-window RMS deviation of y from the float64 truth over all of these evaluations.  The search takes candidates
-in seed order and the frame written is the first whose score stays below 1e-6 (a window error of 1e-6 everywhere would still be 120 dB);
-the search log is committed as tests/golden/wellcond_search.txt.  Nothing here is read by the product path.
+in seed order (a candidate is dropped at its first evaluation above the threshold) and the frame written is the first whose score stays
+below THRESH = 3e-6 over the long confirmation run too (a window error of 3e-6 in EVERY window would still be 110 dB; the typical window of
+such a frame sits at 3e-8).  Frames below 1e-6 were not found: with these weights nearly every random 96 x 160 frame has a spot that rounding-sized
+noise moves by 1e-6 .. 1e-3 (the search log, committed as tests/golden/wellcond_search.txt, shows the distribution).  Nothing here is read by the product path.
 """
 import os
 import sys
@@ -34,6 +36,7 @@ from common import fdn_weights, fixture  # noqa: E402
 
 KEYS, WIN = ("y", "q1", "q2", "q3"), (16, 16, 8, 4)
 TAME = 0.03
+THRESH = 3e-6
 SHAPE = (1, 3, 96, 160)
 
 
@@ -123,12 +126,12 @@ def cmd_search(first, count):
     P32 = fdn_weights(tame=TAME)
     P64 = O.cast_params(P32, torch.float64)
     for seed in range(first, first + count):
-        w, what = score(seed, P32, P64, stop_above=1e-6)
-        print("seed %d: worst window of y %.2e (%s)%s" % (seed, w, what, "" if w > 1e-6 else "   <-- below 1e-6: confirming with 32 more block-noise seeds"), flush=True)
-        if w <= 1e-6:
+        w, what = score(seed, P32, P64, stop_above=THRESH)
+        print("seed %d: worst window of y %s%.2e (%s)%s" % (seed, ">= " if w > THRESH else "", w, what, "" if w > THRESH else "   <-- below %.0e: confirming with 32 block-noise seeds" % THRESH), flush=True)
+        if w <= THRESH:
             w2, what2 = score(seed, P32, P64, n_block=32, n_fft=6, n_f32=5, stop_above=None)
             print("seed %d: confirmed %.2e (%s)" % (seed, w2, what2), flush=True)
-            if w2 <= 1e-6:
+            if w2 <= THRESH:
                 print("chosen seed", seed, flush=True)
                 return seed
     return None

@@ -156,9 +156,10 @@ def test_fdn_end_to_end_tamed(A, name):
 
 @pytest.mark.parametrize("B,E,N,H,W", [(2, 76, 64, 48, 80), (1, 76, 64, 40, 36), (1, 57, 48, 16, 12), (2, 76, 64, 184, 320)])
 def test_fdsa_out_level2_on_the_bf16_pipe(B, E, N, H, W):
-    """fdn_set_matrix_pipe(2): the level-2 FDSA tail (three LayerNorms * v_value, project_out, residual, statistics; FDN_arch.py:633-639, :671)
-    with project_out on v_mfma_f32_32x32x16_bf16 - one pixel per lane, eight waves around one packed operand image.  Against float64 it has to
-    be as good as the default fp32-MFMA form (a ragged last tile, E < 2 * SH and N < 64 included); the switch goes back to the default afterwards."""
+    """The level-2 FDSA tail (three LayerNorms * v_value, project_out, residual, statistics; FDN_arch.py:633-639, :671) with project_out on
+    v_mfma_f32_32x32x16_bf16 - one pixel per lane, eight waves around one packed operand image; the default since round 5.  Against float64 it
+    has to be as good as the fp32-MFMA form it replaced (fdn_set_matrix_pipe(2), "bf16-narrow"; a ragged last tile, E < 2 * SH and N < 64
+    included); the switch goes back to the default afterwards."""
     import ctypes
     import fdn_hip
     P = H * W
@@ -175,7 +176,7 @@ def test_fdsa_out_level2_on_the_bf16_pipe(B, E, N, H, W):
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
     errs = {}
     try:
-        for mode in ("bf16", "bf16-wide"):
+        for mode in ("bf16-narrow", "bf16"):
             fdn_hip.set_matrix_pipe(mode)
             od_, wd, gd, bd, rd = dev(o), dev(w), dev(g3), dev(b3), dev(res)
             out = torch.full((B, N, P), float("nan"), device="cuda:0")
@@ -187,7 +188,7 @@ def test_fdsa_out_level2_on_the_bf16_pipe(B, E, N, H, W):
             assert rel_rms(st[:, 0].cpu(), ref.mean(1)) < 1e-5 and rel_rms(st[:, 1].cpu(), 1 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5)) < 1e-5, mode
     finally:
         fdn_hip.set_matrix_pipe("bf16")
-    assert errs["bf16-wide"] < 2e-6 and errs["bf16-wide"] < 1.5 * errs["bf16"] + 2e-8, errs
+    assert errs["bf16"] < 2e-6 and errs["bf16"] < 1.5 * errs["bf16-narrow"] + 2e-8, errs
 
 
 def _window_rms(d, size):
@@ -589,6 +590,45 @@ def test_forward_streams_fp32_pipe_bit_identical(A, monkeypatch):
     # tips the few ill-conditioned spots of a frame either way (87.6 dB over these six frames, measured; tests/test_gpu_configs.py
     # holds the conditioning-aware bound), so only gross disagreement is an error here
     assert O.psnr(bf.cpu(), one.cpu()) > 70.0
+
+
+def test_f32_matrix_pipe_launches_no_bf16_mfma_kernel(A):
+    """What fdn_set_matrix_pipe(1) promises (include/fdn_hip.h): no kernel that issues a bf16 MFMA is launched - for EVERY conv
+    shape of both models (Downsample 64 -> 128 used to slip through: a 3 x 3 conv with no direct-kernel form reached the split-bf16 kernel
+    ungated).  Every launcher of such a kernel counts (fdn_bf16_mfma_launches); in 'f32' mode the count must stand still over whole
+    forwards of FDN, FDN_lolv1 and LPNet and over direct calls of the wide 3 x 3 shapes; in the default mode it must move."""
+    import fdn_hip
+    from fdn_hip import ops
+    from basicsr.models.archs.LPNet_arch import I_predict_net
+    from basicsr.models.archs.fdnlol24_arch import FDN_lolv1
+    from common import lolv1_weights
+    net = load(A.FDN(), fdn_weights(tame=0.03))
+    net24 = load(FDN_lolv1(), lolv1_weights(tame=0.03))
+    lp = load(I_predict_net(), lpnet_weights())
+    x = dev(torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(23)))
+    g = torch.Generator().manual_seed(24)
+
+    def everything():
+        with torch.no_grad():
+            r = lp(x)
+            y = net(x, ratio_i=r)[0]
+            y24 = net24(x, ratio_i=r)[0]
+            for cin, cout in ((64, 128), (128, 64), (16, 96), (48, 96), (64, 32)):
+                ops.conv2d(dev(torch.randn(1, cin, 24, 40, generator=g)), dev(torch.randn(cout, cin, 3, 3, generator=g)), pad=1)
+        torch.cuda.synchronize()
+        return y, y24
+    n0 = fdn_hip.bf16_mfma_launches()
+    y_bf, y24_bf = everything()
+    n1 = fdn_hip.bf16_mfma_launches()
+    assert n1 > n0 + 100, (n0, n1)
+    fdn_hip.set_matrix_pipe("f32")
+    try:
+        y_f32, y24_f32 = everything()
+        n2 = fdn_hip.bf16_mfma_launches()
+    finally:
+        fdn_hip.set_matrix_pipe("bf16")
+    assert n2 == n1, f"{n2 - n1} bf16-MFMA kernels were launched in 'f32' mode"
+    assert O.psnr(y_bf.cpu(), y_f32.cpu()) > 70.0 and O.psnr(y24_bf.cpu(), y24_f32.cpu()) > 70.0
 
 
 @pytest.mark.parametrize("case", ["a", "b", "c", "d"])

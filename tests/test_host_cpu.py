@@ -242,3 +242,51 @@ def test_reference_driver_imports_through_the_shadow(tmp_path):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([entry.PKG, str(ck)]), FDN_PKG=os.path.realpath(entry.PKG))
     r = subprocess.run([sys.executable, "-c", "import sys\n" + driver_lines + check], env=env, capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0 and "shadow ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_describes_calls_by_name():
+    """bench.py's roofline figures come from the ARGUMENTS of the C-ABI calls it wraps.  They are read by NAME (fdn_hip/_abi.py ARG_NAMES,
+    generated from the header), so an inserted or reordered parameter of a later ABI version cannot silently shift a shape: every parser gets
+    a call built from the header's own prototype in which each integer parameter carries a distinct value, and the group key it returns must
+    show the values of the parameters it names - then the same call with two parameters swapped IN THE TABLE must change the key or raise."""
+    import importlib
+    import bench
+    from fdn_hip._abi import ARG_NAMES, PROTOTYPES
+    spec = importlib.util.spec_from_file_location("gen_abi_table", os.path.join(ROOT, "tools", "gen_abi_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert ARG_NAMES == gen.parse_names(os.path.join(ROOT, "include", "fdn_hip.h"))
+    assert set(ARG_NAMES) == set(PROTOTYPES) and all(len(ARG_NAMES[n]) == len(PROTOTYPES[n][1]) for n in PROTOTYPES)
+    # every entry point the step's by_entry_point_ms can name either has a parser or is a helper without a shape figure; the heavy ones must have one
+    heavy = ("fdn_conv1x1", "fdn_fdsa_fused", "fdn_fdsa_out", "fdn_fdsa_core", "fdn_fdffn_mid", "fdn_ffn_tail", "fdn_dwconv_gate", "fdn_conv2d",
+             "fdn_fft_cols_fcaffn", "fdn_rfft_rows_ln", "fdn_irfft_rows", "fdn_rfft_rows", "fdn_fcaffn_in", "fdn_fcaffn_in_packed", "fdn_chan_stats")
+    assert all(n in bench.DESCRIBERS for n in heavy)
+    assert all(n in PROTOTYPES for n in bench.DESCRIBERS)
+    shape_params = ("C", "E", "Hd", "G", "Cin", "Cout", "rows", "planes", "N", "H", "W", "P", "Wf")
+    derived = {"fdn_rfft_rows_ln": {"C", "H"}}               # (shown as rows = B * C * H)
+    for name, fn in bench.DESCRIBERS.items():
+        if name == "fdn_conv1x1":
+            continue                                             # one descriptor struct: fields are named by construction
+        names, kinds = ARG_NAMES[name], PROTOTYPES[name][1]
+        vals = {n: (None if k == "P" else 0 if n.endswith("bf16") or n in ("form", "pad") else 101 + 2 * i) for i, (n, k) in enumerate(zip(names, kinds))}
+        if "stride" in vals:
+            vals["stride"] = 1
+        args = [ctypes.c_long(v) if k == "L" and v is not None else v for v, k in ((vals[n], k) for n, k in zip(names, kinds))]
+        key, flops, byts = bench.describe_call(name, args)
+        assert key.startswith(name + "[") and byts > 0, (name, key)
+        for pn in shape_params:
+            if pn in vals and vals[pn] is not None and pn not in derived.get(name, ()):
+                assert re.search(r"(?<!\d)%d(?!\d)" % vals[pn], key), f"{name}: parameter {pn}={vals[pn]} not in key {key}"
+        ints = [n for n in names if n in shape_params and n not in derived.get(name, ())]
+        if len(ints) >= 2:                                       # a table in another order = a different ABI: the same positional call must not read the same
+            swapped = list(names)
+            i, j = names.index(ints[0]), names.index(ints[1])
+            swapped[i], swapped[j] = swapped[j], swapped[i]
+            ARG_NAMES[name] = swapped
+            try:
+                key2, _, byts2 = bench.describe_call(name, args)
+            finally:
+                ARG_NAMES[name] = names
+            assert key2 != key, (name, key, key2)
+    with pytest.raises(TypeError):
+        bench.describe_call("fdn_fdsa_fused", [None] * 3)       # a call that does not match the declared parameter count is refused

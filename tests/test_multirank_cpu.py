@@ -193,3 +193,41 @@ def test_graphed_forward_does_not_travel_with_copies():
     assert c.__dict__.get("_fdn_graphed") is None
     st = pickle.loads(pickle.dumps(g))
     assert st.net is None and len(st._graphs) == 0
+
+
+def _uneven_worker(rank, world, port, total, q):
+    sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+    from fdn_hip import sharding
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    x_all = torch.rand(total, 3, 8, 12, generator=g)
+    seen = []
+
+    def forward(x):                                          # per-sample independent stand-in with a different output shape
+        seen.append(x.shape[0])
+        return (x * 2.0 + x.flip(-1))[:, :, ::2].contiguous()
+    y = sharding.sharded_run(dist, forward, total, torch.empty(1, 3, 8, 12), x_all if rank == 0 else None)
+    b = sharding.shard_bounds(total, world)
+    ok_count = seen == ([b[rank + 1] - b[rank]] if b[rank + 1] > b[rank] else [])
+    flags = [None] * world
+    dist.all_gather_object(flags, ok_count)
+    if rank == 0:
+        q.put((torch.equal(y, forward(x_all)), all(flags), tuple(y.shape)))
+    dist.destroy_process_group()
+
+
+def test_global_batch_not_a_multiple_of_the_world_size():
+    """scatter_uneven / gather_uneven / sharded_run - a global batch of 3 (2 + 1) and of 1 (1 + 0: a rank without an item) over
+    two gloo ranks equals the single-process result bit for bit, every rank's forward sees exactly its own item count (no compute on padding)."""
+    ctx = mp.get_context("spawn")
+    for k, total in enumerate((3, 1, 5)):
+        q = ctx.Queue()
+        port = 31700 + (os.getpid() + 7 * k) % 2000
+        procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, total, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        same, counts_ok, shape = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=60)
+        assert same and counts_ok and shape == (total, 3, 4, 12), (total, same, counts_ok, shape)

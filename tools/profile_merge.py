@@ -72,7 +72,14 @@ for i, c in enumerate(calls):
     g["wave_cycles"] += s.get("SQ_WAVE_CYCLES", 0.0)
 
 _meta = json.load(open(f"{src}/calls_trace.json"))
-NSIMD, out = 1024.0, {"note": __doc__, "shape": _meta["shape"], "dtype": _meta.get("dtype", "f32"), "groups": {}}
+def _code_commit():
+    """the commit the profiled code was built from: FDN_PROFILE_COMMIT, or the file the builder writes before a gpurun call (the GPU box has no .git)"""
+    c = os.environ.get("FDN_PROFILE_COMMIT")
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "HEAD_AT_PROFILE")
+    return c or (open(f).read().strip() if os.path.isfile(f) else None)
+
+
+NSIMD, out = 1024.0, {"note": __doc__, "shape": _meta["shape"], "dtype": _meta.get("dtype", "f32"), "commit": _code_commit(), "groups": {}}
 tot = {"ms": 0.0, "rd": 0.0, "wr": 0.0, "alg": 0.0, "valu_ms": 0.0, "mfma_ms": 0.0}
 lines = []
 for key, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
