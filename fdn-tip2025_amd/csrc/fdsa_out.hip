@@ -509,8 +509,9 @@ extern "C" int fdn_fdsa_out(const void* o_, const float* w, const float* gamma3,
     const bool vec_ok = P % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) |
           reinterpret_cast<uintptr_t>(stats_out)) & 15) == 0;
-    if (o_bf16) {                                               // bf16 storage exists in the pixel-pair form only
+    if (o_bf16) {                                               // bf16 storage: the same kernels reading 2-byte elements (storage only: tests/test_gpu_bf16.py)
         if (vec_ok && sh <= 19 && mt == 1) return launch_vec<19, 1, true, true>(a, s);
+        if (fdn_matrix_pipe_wide() && vec_ok && sh > 19 && sh <= 38 && mt <= 2) return launch_vec<38, 2, false, true, 1, 8, true>(a, s);
         if (vec_ok && sh <= 38 && mt <= 2) return launch_vec<38, 2, false, true>(a, s);
         return FDN_ERR_UNSUPPORTED;
     }

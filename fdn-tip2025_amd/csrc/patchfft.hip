@@ -564,6 +564,13 @@ struct FusedArgs {
 #ifndef FDN_FUSED_CELLS
 #define FDN_FUSED_CELLS 1
 #endif
+#ifdef FDN_FUSED_TRACE      // tools/fused_trace.py: s_memtime stamps of every wave of FT_NWG workgroups from the middle of the grid (phase timeline per SIMD)
+constexpr int FT_NWG = 512;
+__device__ unsigned long long g_fused_trace[FT_NWG * 4 * 64];
+#define FTR(i) if (trc && ch < 7) trc[ch * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define FTR(i)
+#endif
 template <int C, bool LN, bool OBF>          // OBF: the (out1|out2|out3|v_value) planes are stored as bf16
 __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArgs a) {
     // (round 4) C <= 32: the hidden tile is ONE plane per channel of (q, k, v, v_value) CELLS - the MFMA rows of a chunk are channel-major,
@@ -588,6 +595,19 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     const unsigned hwo = P * OES;
     const rsrc_t rout = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.out) + (long)b * 4 * E * P * OES), 4u * E * hwo);
 
+#ifdef FDN_FUSED_TRACE
+    unsigned long long* trc = nullptr;
+    {
+        const unsigned base = gridDim.x / 2, rel = blockIdx.x - base;
+        if (rel < (unsigned)FT_NWG && lane == 0) {
+            trc = g_fused_trace + ((long)rel * 4 + wave) * 64;
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            trc[60] = hwid; trc[61] = xcc; trc[62] = blockIdx.x; trc[63] = __builtin_amdgcn_s_memtime();
+        }
+    }
+#endif
     // ---- the wave's strips of the normalised halo tile: B operands of v_mfma_f32_32x32x16_bf16, resident for the whole
     // workgroup.  Lane (pixel ln, half kh) holds channels k = 16 ks + 8 kh + j, normalised and cut into three exact bf16
     // parts (common.hpp: fp32 arithmetic on the bf16 matrix pipe); channels k >= C read 0 and meet zero weights.
@@ -681,6 +701,8 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     // strip, its statistics and `xone` all read 0 there)
     auto mfma_phase = [&](int ch) __attribute__((always_inline)) {
         const fdn_u32x4* wp_ = reinterpret_cast<const fdn_u32x4*>(a.wpk) + ((long)ch * KS) * 64 + lane;      // (!AW_AHEAD: operands straight from L1 / L2)
+        // (round 5, measured: issuing the three strips' chains in turn - three accumulators - changes nothing, 2.315 against 2.288 ms: the phase is not
+        //  bound by the latency of a dependent chain)
 #pragma unroll
         for (int si = 0; si < 3; ++si) {
             if (wave + 4 * si < FNS) {                              // wave-uniform
@@ -719,9 +741,12 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         const int e0 = ch * FEG;
         const int e = e0 + el;
         const bool more = ch + 1 < a.nchunks;                       // uniform
+        FTR(0)
         mfma_phase(ch);
         if (more) stage_fetch(ch + 1);
+        FTR(1)
         __syncthreads();
+        FTR(2)
 
         // ---- rows: depthwise 3x3 (to_hidden_dw, FDN_arch.py:578) + forward row transforms of q, k, v (v_value: see the column phase)
         auto dw_row8 = [&](const float* hp, const float* wk9, float (&o8)[8]) __attribute__((always_inline)) {
@@ -787,7 +812,9 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                 for (int kx = 0; kx < 5; ++kx) S[(t * NP + slot) * PS + kx * KXS + row] = sp[kx];
             }
         }
+        FTR(3)
         __syncthreads();
+        FTR(4)
 
         // ---- columns: thread = (slot, kx): forward, recombine, inverse (as fdsa_core_kernel) ------------------------
         if (tid < NP * 5) {
@@ -851,7 +878,9 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                 st_store8<OBF>(o8, rout, ev < E ? opix + (unsigned)(3 * E + ev) * hwo : OOB, 0);
             }
         }
+        FTR(5)
         __syncthreads();
+        FTR(6)
 
         // ---- inverse rows, 32-byte segments straight to global (out1|out2|out3) --------------------------------------
 #pragma unroll
@@ -863,6 +892,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
             irfft8_row(xk, r8);
             st_store8<OBF>(r8, rout, e < E ? opix + (unsigned)(t * E + e) * hwo : OOB, 0);
         }
+        FTR(7)
         if (more) stage_store();        // taps and gains of the next chunk (this chunk's were last read before the third barrier)
         // (the next chunk's row phase rewrites S behind the barrier at the top of the loop, i.e. after every thread has finished these reads)
     }
@@ -1007,21 +1037,32 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
     FDN_CHECK_ARG(total < 0x7fffffffL);
     const dim3 grid((unsigned)total), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define FDN_FUSED_CASE(CC)                                                                                        \
-    case CC:                                                                                                      \
-        if (stats && out_bf16) hipLaunchKernelGGL((fdsa_fused_kernel<CC, true, true>), grid, block, 0, s, a);     \
-        else if (stats) hipLaunchKernelGGL((fdsa_fused_kernel<CC, true, false>), grid, block, 0, s, a);           \
-        else if (out_bf16) hipLaunchKernelGGL((fdsa_fused_kernel<CC, false, true>), grid, block, 0, s, a);        \
-        else hipLaunchKernelGGL((fdsa_fused_kernel<CC, false, false>), grid, block, 0, s, a);                     \
+#define FDN_FUSED_CASE(KERN, CC)                                                                      \
+    case CC:                                                                                          \
+        if (stats && out_bf16) hipLaunchKernelGGL((KERN<CC, true, true>), grid, block, 0, s, a);      \
+        else if (stats) hipLaunchKernelGGL((KERN<CC, true, false>), grid, block, 0, s, a);            \
+        else if (out_bf16) hipLaunchKernelGGL((KERN<CC, false, true>), grid, block, 0, s, a);         \
+        else hipLaunchKernelGGL((KERN<CC, false, false>), grid, block, 0, s, a);                      \
         break;
     switch (C) {
-        FDN_FUSED_CASE(24)
-        FDN_FUSED_CASE(32)
-        FDN_FUSED_CASE(48)
-        FDN_FUSED_CASE(64)
+        FDN_FUSED_CASE(fdsa_fused_kernel, 24)
+        FDN_FUSED_CASE(fdsa_fused_kernel, 32)
+        FDN_FUSED_CASE(fdsa_fused_kernel, 48)
+        FDN_FUSED_CASE(fdsa_fused_kernel, 64)
         default: return FDN_ERR_UNSUPPORTED;
     }
 #undef FDN_FUSED_CASE
     fdn_note_bf16_launch();
     return fdn_launch_status();
 }
+
+#ifdef FDN_FUSED_TRACE
+extern "C" int fdn_debug_fused_trace(void* host, long bytes) {          // trace builds only (tools/fused_trace.py); not part of the ABI
+    if (bytes > (long)sizeof(unsigned long long) * FT_NWG * 4 * 64) return FDN_ERR_ARG;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fused_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? FDN_OK : FDN_ERR_LAUNCH;
+}
+extern "C" int fdn_debug_fused_trace_clear(void) {
+    static unsigned long long z[FT_NWG * 4 * 64];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fused_trace), z, sizeof(z), 0, hipMemcpyHostToDevice) == hipSuccess ? FDN_OK : FDN_ERR_LAUNCH;
+}
+#endif

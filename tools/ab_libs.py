@@ -78,3 +78,14 @@ for k in kernels:
         for p, l in libs:
             res[p].append(timeit(l, k))
     print(f"L{lvl} {k:6s} " + "   ".join(f"{p}: {statistics.median(v):.3f} ms (min {min(v):.3f})" for p, v in res.items()), flush=True)
+    if len(libs) > 1:                  # do the builds agree?  (same inputs: the output buffer of the kernel after each build's call)
+        outs = []
+        for p, l in libs:
+            ob = {"mid": out_h, "gate": out_h, "tail": out_c, "out": out_c, "core": out_4e, "fused": out_4e}[k]
+            ob.fill_(float("nan"))
+            call(l, k)
+            torch.cuda.synchronize()
+            outs.append(ob.clone())
+        for (p, _), o in zip(libs[1:], outs[1:]):
+            same = torch.equal(outs[0], o)
+            print(f"         {paths[0]} vs {p}: bit-identical {same}" + ("" if same else f", max |diff| {(outs[0] - o).abs().max().item():.3e}, nan {int(torch.isnan(o).sum())}"), flush=True)
