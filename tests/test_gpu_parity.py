@@ -143,8 +143,15 @@ def test_lpnet_real_weights(A):
     assert torch.allclose(y2.cpu(), fx["y_736x1280_seed52"], rtol=0, atol=5e-6)
 
 
-@pytest.mark.parametrize("name", ["fdn_tamed_64", "fdn_tamed_96x160"])
+@pytest.mark.parametrize("name", ["fdn_tamed_64", "fdn_tamed_96x160_wc"])
 def test_fdn_end_to_end_tamed(A, name):
+    """Fixed 100 dB floor against the reference's own outputs - on frames WITHOUT ill-conditioned spots.  With the tamed synthetic weights nearly
+    every random 96 x 160 frame has a spot where a spectrum bin of an FDSA block lies within fp32 rounding of zero, so that one rounding decides
+    its phase and 1e-6 .. 1e-3 of a 16 x 16 window of y (tests/golden/wellcond_search.txt; DESIGN.md, parity policy): a fixed floor there pins the
+    luck of one evaluation - `fdn_tamed_96x160` is such a frame and is held window by window in the test below.  `fdn_tamed_96x160_wc` is the
+    first frame of a committed seed search (tests/golden/make_golden_wellcond.py: float64 oracle with rounding-sized noise on every
+    TransformerBlock output / every forward FFT, fp32 oracle under one-ulp input changes) whose worst window stays at rounding level in every
+    evaluation: 2.3e-6 over the 49 of the search, 3.1e-6 over the 145 of its conditioning file; on it a healthy path cannot fall below ~115 dB."""
     fx = fixture(name)
     m = load(A.FDN(), fdn_weights(tame=float(fx["tame"])))
     with torch.no_grad():
@@ -196,13 +203,16 @@ def _window_rms(d, size):
     return d.double().pow(2).reshape(B, C, H // size, size, W // size, size).mean((1, 3, 5)).sqrt().reshape(-1)
 
 
-@pytest.mark.parametrize("name", ["fdn_tamed_64", "fdn_tamed_96x160"])
+@pytest.mark.parametrize("name", ["fdn_tamed_64", "fdn_tamed_96x160", "fdn_tamed_96x160_wc"])
 def test_fdn_end_to_end_tamed_conditioning(A, name):
-    """The same forwards held per WINDOW to what fp32 can do there (the footing of test_config1_736x1280_frame_matches_reference): against the
-    float64 truth a window may be off by 4 x the worst of the reference's own error and the measured fp32 susceptibility of THAT window
-    (tests/golden/make_golden_small_cond.py: five fp32 oracle evaluations, eight float64 evaluations with emulated FFT rounding), plus a few
-    ulp.  The 96 x 160 frame has one ill-conditioned spot (windows 16, 17, 26, 27 of y: 1e-6 .. 6e-5 under rounding-sized noise, 3e-8 elsewhere):
-    a fixed PSNR floor there tests the luck of one rounding, this test the arithmetic."""
+    """The end-to-end forwards held per WINDOW to what fp32 can do there (the footing of test_config1_736x1280_frame_matches_reference) - THE gate
+    for `fdn_tamed_96x160`.  Against the float64 truth a window may be off by 4 x the worst of: the reference's own error there,
+    and the measured susceptibility of THAT window - five fp32 oracle evaluations (the frame and one-ulp perturbations), eight float64 evaluations
+    with the rounding of an fp32 FFT emulated (make_golden_small_cond.py), and 96 float64 evaluations with rounding-sized white noise (2e-7 / 3e-7 of
+    the rms) on every TransformerBlock output (make_golden_wellcond.py `blocknoise`) - plus a few ulp.  None of the measures involves this library.
+    The 96 x 160 frame has three discrete states under such noise (windows 27 / 17 / 26 / 16 at 5.6e-5, 50 / 40 at 8.5e-6, 12 / 2 / 13 / 3 at 3.2e-4:
+    one spectrum bin each whose sign rounding decides); an fp32 evaluation lands in some of them, which ones is a matter of its last bits.  Every
+    other window - and every window of the other two frames - has to sit at rounding level."""
     fx, cond = fixture(name), fixture(name + "_cond")
     m = load(A.FDN(), fdn_weights(tame=float(fx["tame"])))
     with torch.no_grad():
@@ -211,6 +221,8 @@ def test_fdn_end_to_end_tamed_conditioning(A, name):
         truth = cond[key + "_f64"]
         e_hip, e_ref = _window_rms(got.cpu().double() - truth, size), _window_rms(fx[key].double() - truth, size)
         susc = torch.maximum(cond[key + "_susc"].max(0).values, cond[key + "_noise"].max(0).values)
+        if key + "_blocknoise" in cond:
+            susc = torch.maximum(susc, cond[key + "_blocknoise"].max(0).values)
         allow = 4.0 * torch.maximum(e_ref, susc) + 5e-8
         bad = (e_hip > allow).nonzero().flatten().tolist()
         assert not bad, f"{name}.{key}: windows {bad[:8]}: HIP {e_hip[bad[:8]].tolist()} allowed {allow[bad[:8]].tolist()}"

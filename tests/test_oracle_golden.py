@@ -102,7 +102,7 @@ def test_lpnet_real_weights():
     assert torch.allclose(y, fx["y"], rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["fdn_tamed_64", "fdn_tamed_96x160"])
+@pytest.mark.parametrize("name", ["fdn_tamed_64", "fdn_tamed_96x160", "fdn_tamed_96x160_wc"])
 def test_fdn_end_to_end_tamed(name):
     fx = fixture(name)
     sd = fdn_weights(tame=float(fx["tame"]))
