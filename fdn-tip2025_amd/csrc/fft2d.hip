@@ -1259,11 +1259,21 @@ int launch_cols(ColArgs a, long planes, fdn_stream_t stream) {
 //   LDS: Y[row][k1][n2] with k1 stride P + 1 (conflict-free for both access directions), reused as Z[row][k]; then the
 //   transposed twiddles tw2[(n2 - 1) R1 + k1] = W_M^{n2 k1} and the split twiddles W_W^k, k <= M.
 // ------------------------------------------------------------------------------------------
+// (round 5) R1 = 35 - the reference's own LOL-Blur frames, 640 x 1120: W = 1120 / 560 / 280 = 2 x 35 x {16, 8, 4} - does not fit eight row groups: 35 x 8 = 280
+// second-stage jobs for 256 threads and 85 KB of LDS.  The number of row groups NG is therefore part of the plan: the largest that keeps R1 * NG <= 256
+// jobs AND two workgroups per CU (<= 80 KB): 7 at P = 16 / 8 (14 / 28 rows per workgroup, 245 jobs, 75 KB), 6 at P = 4 (48 rows, 210 jobs, 69 KB).
+constexpr int row_plan_groups(int R1, int P) {
+    int ng = 8;
+    while (ng > 1 && (R1 * ng > 256 || ((long)ng * (32 / P) * R1 * (P + 1) + (P - 1) * R1 + R1 * P + 1) * 8 > 80 * 1024)) --ng;
+    return ng;
+}
 template <int R1, int P>
 struct RowPlan {
-    static constexpr int M = R1 * P, W = 2 * M, Wf = M + 1, RW = 256 / P, CJ = 32 / P, NG = 8, PS = P + 1, RS = R1 * PS, NJ = R1 * NG;
+    static constexpr int NG = row_plan_groups(R1, P);
+    static constexpr int M = R1 * P, W = 2 * M, Wf = M + 1, CJ = 32 / P, RW = NG * CJ, PS = P + 1, RS = R1 * PS, NJ = R1 * NG;
     static constexpr int NTW = (P - 1) * R1 + Wf;
     static constexpr size_t lds = ((size_t)RW * RS + NTW) * sizeof(float2);
+    static_assert(RW * P <= 256 && NJ <= 256 && CJ * P <= 32, "first stage: one thread per (row, n2); second stage: one per (row group, k1) with 32 values");
 };
 
 // LN: the input rows are planes of x [B][C][H][W] and the transform is taken of the channel LayerNorm of x
@@ -1290,8 +1300,8 @@ __global__ __launch_bounds__(256, 2) void rfft_rows_rp_kernel(const float* __res
     const long row0 = (long)blockIdx.x * RW;
     const int nrow = (int)min((long)RW, R - row0);
     {
-        const int n2 = tid & (P - 1), rw = tid / P;
-        const int rwc = rw < nrow ? rw : nrow - 1;                           // rows past the end shadow the last one
+        const int n2 = tid & (P - 1), rw = tid / P < RW ? tid / P : RW - 1;  // (plans with RW P < 256: the threads past the last row shadow it - same
+        const int rwc = rw < nrow ? rw : nrow - 1;                           //  values to the same cells); rows past the end shadow the last one
         const __amdgpu_buffer_rsrc_t rin = cols_rsrc(in + row0 * W, (long)nrow * W * 4);
         const unsigned voff = (unsigned)(rwc * W + 2 * n2) * 4u;
         f2 u[R1];
@@ -1458,8 +1468,9 @@ __global__ __launch_bounds__(256, 2) void irfft_rows_rp_kernel(const float2* __r
     __syncthreads();
     {
         const int n2 = tid & (P - 1), rw = tid / P;
+        const int rwl = rw < RW ? rw : RW - 1;
         f2 u[R1];
-        sfor<0, R1>([&](auto k) { u[decltype(k)::value] = Y[rw * RS + decltype(k)::value * PS + n2]; });
+        sfor<0, R1>([&](auto k) { u[decltype(k)::value] = Y[rwl * RS + decltype(k)::value * PS + n2]; });
         fftr::dft_nat<R1, true>(u);
         if (rw < nrow) {
             const __amdgpu_buffer_rsrc_t ro = cols_rsrc(out + row0 * W, (long)nrow * W * 4);
@@ -1550,6 +1561,8 @@ bool rows_plan(int W, int* R1, int* P) {
             if (W == 2 * r * p) { *R1 = r; *P = p; return true; }
     for (int p : {16, 8})                                   // LOL-v1 padded: W = 608 / 304 (19 x 16, 19 x 8; 152 = 2 x 19 x 4 stays generic)
         if (W == 2 * 19 * p) { *R1 = 19; *P = p; return true; }
+    for (int p : {16, 8, 4})                                // LOL-Blur frames (inference_fdn_lolblur.py:16-17): W = 1120 / 560 / 280
+        if (W == 2 * 35 * p) { *R1 = 35; *P = p; return true; }
     return false;
 }
 #define FDN_ROWS_DISPATCH(CALL)                                        \
@@ -1562,6 +1575,9 @@ bool rows_plan(int W, int* R1, int* P) {
         case 30 * 64 + 8: return CALL(30, 8);                          \
         case 19 * 64 + 16: return CALL(19, 16);                        \
         case 19 * 64 + 8: return CALL(19, 8);                          \
+        case 35 * 64 + 16: return CALL(35, 16);                        \
+        case 35 * 64 + 8: return CALL(35, 8);                          \
+        case 35 * 64 + 4: return CALL(35, 4);                          \
         default: break;                                                \
     }
 

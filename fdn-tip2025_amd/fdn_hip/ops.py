@@ -432,7 +432,7 @@ def rfft_rows(x, pitch=None):
     return out
 
 
-ROWS_PLANNED_W = tuple(2 * r * p for r in (20, 30) for p in (32, 16, 8)) + (608, 304)     # widths fdn_rfft_rows_ln has a form for (19 x 16, 19 x 8: LOL-v1 padded)
+ROWS_PLANNED_W = tuple(2 * r * p for r in (20, 30) for p in (32, 16, 8)) + (608, 304) + (1120, 560, 280)     # widths fdn_rfft_rows_ln has a form for (19 x 16, 19 x 8: LOL-v1 padded; 35 x 16 / 8 / 4: LOL-Blur frames)
 
 
 def rows_ln_ok(x):

@@ -129,11 +129,11 @@ def test_sincos_whole_float_range(ops):
     assert torch.isnan(sn).all() and torch.isnan(cs).all()
 
 
-PLANNED_W = [1280, 640, 320, 1920, 960, 480, 608, 304]
+PLANNED_W = [1280, 640, 320, 1920, 960, 480, 608, 304, 1120, 560, 280]      # (35 x 16 / 8 / 4: 7 / 7 / 6 row groups per workgroup, a partly filled first stage)
 
 
 @pytest.mark.parametrize("W", PLANNED_W)
-@pytest.mark.parametrize("rows", [37, 64, 3])
+@pytest.mark.parametrize("rows", [37, 64, 3, 113])
 def test_rfft_rows_planned(ops, W, rows):
     """Row r2c with a compile-time plan (half-length 20|30 x 32|16|8), incl. a last workgroup with fewer rows than it holds."""
     x = _rnd(1, 1, rows, W, seed=W + rows)
@@ -166,7 +166,7 @@ def test_rows_round_trip_at_bench_shape(ops):
     assert rel_rms(back.cpu(), x) < 2e-6
 
 
-@pytest.mark.parametrize("C,H,W", [(32, 9, 1280), (64, 5, 640), (8, 11, 320), (3, 4, 960), (24, 6, 608), (48, 5, 304)])
+@pytest.mark.parametrize("C,H,W", [(32, 9, 1280), (64, 5, 640), (8, 11, 320), (3, 4, 960), (24, 6, 608), (48, 5, 304), (32, 9, 1120), (64, 13, 560), (8, 61, 280)])
 def test_rfft_rows_ln_equals_layernorm_then_rfft(ops, C, H, W):
     """Row r2c with the channel LayerNorm applied on load against fdn_layernorm_chan -> fdn_rfft_rows and against float64."""
     B = 2
