@@ -608,6 +608,8 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         }
     }
 #endif
+    // (round 5, measured and dropped: an L2 warm-up of the tile 2 x CUs blocks ahead - one dword per line of its body into a register nothing reads -
+    //  changes nothing: 2.322 against 2.306 ms, level 2 1.441 against 1.390, although the build without the strip loads runs 12 % / 10 % faster)
     // ---- the wave's strips of the normalised halo tile: B operands of v_mfma_f32_32x32x16_bf16, resident for the whole
     // workgroup.  Lane (pixel ln, half kh) holds channels k = 16 ks + 8 kh + j, normalised and cut into three exact bf16
     // parts (common.hpp: fp32 arithmetic on the bf16 matrix pipe); channels k >= C read 0 and meet zero weights.
