@@ -608,6 +608,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         }
     }
 #endif
+    // (and: s_setprio 2 / 3 for the prologue - a fresh workgroup's waves are the youngest of their SIMDs - 2.380 / 2.375 against 2.322 ms: slower)
     // (round 5, measured and dropped: an L2 warm-up of the tile 2 x CUs blocks ahead - one dword per line of its body into a register nothing reads -
     //  changes nothing: 2.322 against 2.306 ms, level 2 1.441 against 1.390, although the build without the strip loads runs 12 % / 10 % faster)
     // ---- the wave's strips of the normalised halo tile: B operands of v_mfma_f32_32x32x16_bf16, resident for the whole
