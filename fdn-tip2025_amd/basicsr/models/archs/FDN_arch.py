@@ -364,8 +364,12 @@ def _spectral_mlps(y, process1, process2, H, W):
     """rfft2 -> (|.|, angle) -> per-bin 1x1 MLPs -> polar -> column iFFT (FDN_arch.py:90-97)."""
     z = ops.rfft_rows(y)
     mag, pha = ops.fft_cols_fwd(z, True, True, rd_before=False, fix_real=True)
-    mag = _mlp2(process1, mag)
-    pha = _mlp2(process2, pha)
+    if ops.SPECTRAL_MLP_FUSED and mag.shape[1] in ops.SPECTRAL_MLP_C:              # both MLPs in one launch, in place (the four 1x1 convs read and write 4 C planes each)
+        ops.spectral_mlp2(mag, pha, _w(process1[0].weight), _w(process1[0].bias), _w(process1[2].weight), _w(process1[2].bias),
+                          _w(process2[0].weight), _w(process2[0].bias), _w(process2[2].weight), _w(process2[2].bias), slope=0.1)
+    else:
+        mag = _mlp2(process1, mag)
+        pha = _mlp2(process2, pha)
     return ops.fft_cols_inv_polar(mag, pha, H, W // 2 + 1)
 
 

@@ -200,6 +200,83 @@ __global__ __launch_bounds__(256) void convT_kernel(const float* __restrict__ x,
     }
 }
 
+// (round 5) The same transposed conv with a thread per INPUT pixel: its 2 x 2 output quad needs the 3 x 3 input window around it and every one of the
+// 16 taps exactly once, so the tap of an FMA no longer depends on the lane's output parity - the weights become wave-uniform LDS broadcasts
+// ([ci][tap][OCB] rows of 16 bytes) instead of per-lane gathers, no lane multiplies a masked zero, and a lane stores 8-byte row pairs.  Each output
+// sums its four taps in the order of convT_kernel (ky0, kx0), (ky0, kx0 + 2), (ky0 + 2, kx0), (ky0 + 2, kx0 + 2): same bits.
+// MAR's two up-convs (24 -> 12 at 368 x 640, 48 -> 24 at 184 x 320): 0.90 + 0.31 ms with convT_kernel.
+template <int OCB_>
+__global__ __launch_bounds__(256) void convT_quad_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int Cin, int H, int W, int Cout, int act) {
+    static_assert(OCB_ % 4 == 0, "weight rows are read as 16-byte words");
+    extern __shared__ __attribute__((aligned(16))) float wl[];          // [ci][tap = ky * 4 + kx][OCB_]
+    unsigned bx, by, bz;
+    fdn_xcd_block3(bx, by, bz);
+    const int oc0 = by * OCB_, b = bz;
+    const int nvalid = min(OCB_, Cout - oc0);
+    for (int i = threadIdx.x; i < Cin * 16 * OCB_; i += 256) {
+        const int o = i % OCB_, t = (i / OCB_) % 16, ci = i / (OCB_ * 16);
+        wl[i] = o < nvalid ? w[((long)ci * Cout + oc0 + o) * 16 + t] : 0.f;
+    }
+    __syncthreads();
+    const long hw = (long)H * W;
+    const long ip = (long)bx * 256 + threadIdx.x;
+    const bool live = ip < hw;
+    const int iy = live ? (int)(ip / W) : 0, ix = live ? (int)(ip - (long)iy * W) : 0;
+    // the 3 x 3 window: offsets relative to the plane, 0 and a cleared flag outside the image
+    int off[9];
+    unsigned ok = 0;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) {
+        const int y = iy - 1 + d / 3, xx = ix - 1 + d % 3;
+        const bool v = live && y >= 0 && y < H && xx >= 0 && xx < W;
+        off[d] = v ? y * W + xx : 0;
+        ok |= (v ? 1u : 0u) << d;
+    }
+    float acc[4][OCB_];                                                    // [2 py + px][channel]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int o = 0; o < OCB_; ++o) acc[q][o] = 0.f;
+    const float* xc = x + (long)b * Cin * hw;
+    for (int ci = 0; ci < Cin; ++ci, xc += hw) {
+        float v[9];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) v[d] = xc[off[d]];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) v[d] = ((ok >> d) & 1u) ? v[d] : 0.f;
+        const float* wc = wl + ci * 16 * OCB_;
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int ky0 = py ? 0 : 1, kx0 = px ? 0 : 1;             // (oy + 1) & 1 with oy = 2 iy + py
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ky = ky0 + 2 * (j >> 1), kx = kx0 + 2 * (j & 1);
+                    // oy = 2 iy' - 1 + ky  =>  iy' = iy + (py + 1 - ky) / 2: window row 1 + (py + 1 - ky) / 2 (exact: the difference is even)
+                    const int wy = 1 + (py + 1 - ky) / 2, wx = 1 + (px + 1 - kx) / 2;
+                    const float vv = v[wy * 3 + wx];
+                    const float* wp = wc + (ky * 4 + kx) * OCB_;
+#pragma unroll
+                    for (int o = 0; o < OCB_; ++o) acc[2 * py + px][o] = fmaf(vv, wp[o], acc[2 * py + px][o]);
+                }
+            }
+    }
+    if (!live) return;
+    const int OW = 2 * W;
+    const long OP = 4 * hw;
+#pragma unroll
+    for (int o = 0; o < OCB_; ++o) {
+        if (o < nvalid) {                                                  // (no `break`: the accumulators keep static register indices)
+            const float bb = bias ? bias[oc0 + o] : 0.f;
+            float* op = out + ((long)b * Cout + oc0 + o) * OP + (long)(2 * iy) * OW + 2 * ix;
+            *reinterpret_cast<float2*>(op) = make_float2(apply_act(acc[0][o] + bb, act), apply_act(acc[1][o] + bb, act));
+            *reinterpret_cast<float2*>(op + OW) = make_float2(apply_act(acc[2][o] + bb, act), apply_act(acc[3][o] + bb, act));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, float* __restrict__ out, long planes, int H,
                                                        int W, int OH, int OW, int mode, int r) {
     // grid = (column blocks, output rows, output planes): no per-element division (the flat index form spent ~100 instructions
@@ -342,6 +419,56 @@ __global__ __launch_bounds__(256) void scale_batch_kernel(float* __restrict__ x,
     if (idx < total) x[idx] *= ratio[idx / per_b];
 }
 
+// The per-bin MLPs of MAR's Fourier blocks (FDN_arch.py:93-94, :142-143): mag <- W2m lrelu(W1m mag + b1m) + b2m, pha likewise, in place, both in
+// one launch.  As four fdn_conv1x1 launches these cost 0.43 ms per level-1 FreBlock (48 planes read and 48 written twice over, on MFMA tiles a
+// quarter full at C = 12); here a thread owns one bin: its C values live in registers, every plane is read and written once - 4 C^2 FMAs per
+// bin against 16 C bytes, i.e. the HBM rate of 4 C planes.  The weights wait in LDS ([W1 | W2 transposed | b1 | b2] per MLP, read at wave-uniform
+// addresses = broadcasts of 16 bytes): as scalar operands they need 2 C registers per hidden unit, and the compiler spilled 322 of them at C = 48.
+template <int C>
+__global__ __launch_bounds__(256) void spectral_mlp2_kernel(float* __restrict__ mag, float* __restrict__ pha, const float* __restrict__ w1m,
+                                                            const float* __restrict__ b1m, const float* __restrict__ w2m,
+                                                            const float* __restrict__ b2m, const float* __restrict__ w1p,
+                                                            const float* __restrict__ b1p, const float* __restrict__ w2p,
+                                                            const float* __restrict__ b2p, long P, float slope) {
+    constexpr int WS = 2 * C * C + 2 * C;                            // floats per MLP
+    __shared__ __attribute__((aligned(16))) float wsh[2 * WS];
+    for (int i = threadIdx.x; i < 2 * WS; i += 256) {
+        const int m = i / WS, r = i - m * WS;
+        const float* w1 = m ? w1p : w1m; const float* w2 = m ? w2p : w2m; const float* b1 = m ? b1p : b1m; const float* b2 = m ? b2p : b2m;
+        float v;
+        if (r < C * C) v = w1[r];                                    // W1[j][i]
+        else if (r < 2 * C * C) { const int q = r - C * C, j = q / C, k = q - j * C; v = w2[k * C + j]; }      // W2 transposed: [j][k]
+        else if (r < 2 * C * C + C) v = b1[r - 2 * C * C];
+        else v = b2[r - 2 * C * C - C];
+        wsh[i] = v;
+    }
+    __syncthreads();
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const long base = (long)blockIdx.y * C * P + p;
+    auto mlp = [&](float* __restrict__ t, const float* __restrict__ ws) __attribute__((always_inline)) {
+        const float* w1 = ws, *w2t = ws + C * C, *b1 = ws + 2 * C * C, *b2 = b1 + C;
+        float v[C], o[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = t[base + (long)i * P];
+#pragma unroll
+        for (int k = 0; k < C; ++k) o[k] = b2[k];
+#pragma unroll 1
+        for (int j = 0; j < C; ++j) {
+            float s = b1[j];
+#pragma unroll
+            for (int i = 0; i < C; ++i) s = fmaf(w1[j * C + i], v[i], s);
+            const float h = s > 0.f ? s : s * slope;
+#pragma unroll
+            for (int k = 0; k < C; ++k) o[k] = fmaf(w2t[j * C + k], h, o[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) t[base + (long)k * P] = o[k];
+    };
+    mlp(mag, wsh);
+    mlp(pha, wsh + WS);
+}
+
 // gamma curve 1 - (1 - x)^(40 * i)   (MAR.forward, FDN_arch.py:282-284)
 __global__ __launch_bounds__(256) void gamma_curve_kernel(const float* __restrict__ x, const float* __restrict__ im,
                                                           float* __restrict__ out, float scale, long total) {
@@ -453,6 +580,11 @@ extern "C" int fdn_conv_transpose4x4s2(const float* x, const float* w, const flo
                                        int W, int Cout, int act, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cout >= 12 && (size_t)Cin * 16 * 12 * sizeof(float) <= 48 * 1024 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {      // quad form, 12 channels per block
+        hipLaunchKernelGGL(convT_quad_kernel<12>, dim3(cdiv((long)H * W, 256), cdiv(Cout, 12), B), dim3(256), (size_t)Cin * 16 * 12 * sizeof(float), s,
+                           x, w, bias, out, Cin, H, W, Cout, act);
+        return fdn_launch_status();
+    }
     if (Cout > 8 && (size_t)Cin * 16 * 16 * sizeof(float) <= 64 * 1024) {
         hipLaunchKernelGGL(convT_kernel<16>, dim3(cdiv(4L * H * W, 256), cdiv(Cout, 16), B), dim3(256), (size_t)Cin * 16 * 16 * sizeof(float),
                            s, x, w, bias, out, Cin, H, W, Cout, act);
@@ -539,6 +671,21 @@ extern "C" int fdn_scale_batch(float* x, const float* ratio, int B, long per_bat
     FDN_CHECK_ARG(x && ratio && B > 0 && per_batch > 0);
     hipLaunchKernelGGL(scale_batch_kernel, dim3(cdiv(B * per_batch, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                        ratio, per_batch, B * per_batch);
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_spectral_mlp2(float* mag, float* pha, const float* w1m, const float* b1m, const float* w2m, const float* b2m,
+                                 const float* w1p, const float* b1p, const float* w2p, const float* b2p, int B, int C, long P, float slope,
+                                 fdn_stream_t stream) {
+    FDN_CHECK_ARG(mag && pha && w1m && b1m && w2m && b2m && w1p && b1p && w2p && b2p && B > 0 && C > 0 && P > 0 && B < 65536);
+    const dim3 grid((unsigned)cdiv(P, 256), (unsigned)B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (C) {
+        case 12: hipLaunchKernelGGL(spectral_mlp2_kernel<12>, grid, dim3(256), 0, s, mag, pha, w1m, b1m, w2m, b2m, w1p, b1p, w2p, b2p, P, slope); break;
+        case 24: hipLaunchKernelGGL(spectral_mlp2_kernel<24>, grid, dim3(256), 0, s, mag, pha, w1m, b1m, w2m, b2m, w1p, b1p, w2p, b2p, P, slope); break;
+        case 48: hipLaunchKernelGGL(spectral_mlp2_kernel<48>, grid, dim3(256), 0, s, mag, pha, w1m, b1m, w2m, b2m, w1p, b1p, w2p, b2p, P, slope); break;
+        default: return FDN_ERR_UNSUPPORTED;
+    }
     return fdn_launch_status();
 }
 

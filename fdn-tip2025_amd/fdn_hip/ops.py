@@ -585,6 +585,21 @@ def scale_batch_(x, ratio):
     return x
 
 
+SPECTRAL_MLP_C = (12, 24, 48)      # widths fdn_spectral_mlp2 has a form for (MAR's three levels, both models)
+SPECTRAL_MLP_FUSED = True           # False: the four fdn_conv1x1 launches per block instead (A/B runs: bench.py --unfused-mlps)
+
+
+def spectral_mlp2(mag, pha, w1m, b1m, w2m, b2m, w1p, b1p, w2p, b2p, slope=0.1):
+    """mag <- process1(mag), pha <- process2(pha) IN PLACE: the two per-bin Conv1x1 -> LeakyReLU -> Conv1x1 MLPs of a FreBlock / fourier_fuse in one
+    launch (fdn_spectral_mlp2; FDN_arch.py:93-94, :142-143).  mag, pha [B, C, H, Wf] contiguous."""
+    B, C = mag.shape[0], mag.shape[1]
+    P = mag[0, 0].numel()
+    check(lib().fdn_spectral_mlp2(_flat(mag, "mag"), _flat(pha, "pha"), _flat(w1m.reshape(C, C), "w1m"), _flat(b1m, "b1m"), _flat(w2m.reshape(C, C), "w2m"),
+                                  _flat(b2m, "b2m"), _flat(w1p.reshape(C, C), "w1p"), _flat(b1p, "b1p"), _flat(w2p.reshape(C, C), "w2p"), _flat(b2p, "b2p"),
+                                  B, C, ctypes.c_long(P), ctypes.c_float(slope), stream()), "fdn_spectral_mlp2")
+    return mag, pha
+
+
 def gamma_curve(x, i_map, scale=40.0):
     out = torch.empty_like(x)
     check(lib().fdn_gamma_curve(_flat(x, "x"), _flat(i_map, "i_map"), _flat(out, "out"), ctypes.c_float(scale),

@@ -286,6 +286,12 @@ int fdn_avgpool3s2(const float* x, float* out, long planes, int H, int W, fdn_st
 int fdn_global_avgpool(const float* x, float* out, long planes, long P, fdn_stream_t stream);
 int fdn_se_apply(const float* y, const float* gate, const float* shortcut, float* out, long planes, long P,
                  fdn_stream_t stream);
+/* ABI 12.  The two per-bin MLPs of a FreBlock / fourier_fuse in ONE launch, in place: mag <- process1(mag), pha <- process2(pha), each
+ * Conv2d(C, C, 1) -> LeakyReLU(slope) -> Conv2d(C, C, 1) with bias over the C channels of a spectrum bin (FDN_arch.py:79-94, :127-143).
+ * mag, pha [B][C][P] (P bins per plane); w1*, w2* [C][C], b1*, b2* [C].  C in {12, 24, 48}; other widths return FDN_ERR_UNSUPPORTED
+ * (four fdn_conv1x1 calls do the same). */
+int fdn_spectral_mlp2(float* mag, float* pha, const float* w1m, const float* b1m, const float* w2m, const float* b2m, const float* w1p,
+                      const float* b1p, const float* w2p, const float* b2p, int B, int C, long P, float slope, fdn_stream_t stream);
 /* x[b] *= ratio[b] (FDN_arch.py:213-219); out = 1-(1-x)^(scale*i_map) (FDN_arch.py:282-284). */
 int fdn_scale_batch(float* x, const float* ratio, int B, long per_batch, fdn_stream_t stream);
 int fdn_gamma_curve(const float* x, const float* i_map, float* out, float scale, long total, fdn_stream_t stream);

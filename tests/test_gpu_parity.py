@@ -491,7 +491,7 @@ def test_conv3x3_tiled_options(A, Cin, Cout, H, W, act, res_before):
     assert rel_rms(plain.cpu(), torch.nn.functional.conv2d(x.double(), w.double(), padding=1)) < 2e-6
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W", [(24, 12, 9, 13), (48, 24, 8, 16), (6, 5, 7, 9)])
+@pytest.mark.parametrize("Cin,Cout,H,W", [(24, 12, 9, 13), (48, 24, 8, 16), (6, 5, 7, 9), (24, 12, 46, 80), (24, 20, 5, 77), (48, 24, 23, 40)])
 def test_conv_transpose4x4s2(A, Cin, Cout, H, W):
     from fdn_hip import ops
     x, w, b = _rnd(2, Cin, H, W, seed=1), _rnd(Cin, Cout, 4, 4, seed=2) / (4 * Cin ** 0.5), _rnd(Cout, seed=3)
@@ -745,3 +745,27 @@ def test_resample_bilinear_matches_torch(A, H, W):
         dn = ops.resample(dev(x), ops.RS_BILINEAR_HALF)
         refd = torch.nn.functional.interpolate(x.double(), scale_factor=0.5, mode="bilinear", align_corners=False)
         assert rel_rms(dn.cpu(), refd) < 1e-6
+
+
+@pytest.mark.parametrize("C,H,Wf", [(12, 38, 21), (24, 17, 33), (48, 9, 161), (12, 738, 642)])
+def test_spectral_mlp2_matches_float64_and_the_four_convs(C, H, Wf):
+    """fdn_spectral_mlp2 (ABI 12): process1(mag), process2(pha) of a FreBlock / fourier_fuse (FDN_arch.py:93-94, :142-143) in one launch, in place,
+    against float64 and against the four fdn_conv1x1 launches it replaces (the last shape: fourier_fuse's 738 x 642 level-1 map, ragged last block)."""
+    from fdn_hip import ACT_LEAKY, ops
+    B = 2
+    g = torch.Generator().manual_seed(C + H)
+    mag, pha = torch.rand(B, C, H, Wf, generator=g) * 3, (torch.rand(B, C, H, Wf, generator=g) * 2 - 1) * 3.14159
+    W = [torch.randn(C, C, generator=g) / C ** 0.5 for _ in range(4)]
+    b = [torch.randn(C, generator=g) * 0.1 for _ in range(4)]
+
+    def ref(t, w1, b1, w2, b2):
+        h = torch.einsum("jc,bchw->bjhw", w1.double(), t.double()) + b1.double()[None, :, None, None]
+        h = torch.where(h > 0, h, 0.1 * h)
+        return torch.einsum("kj,bjhw->bkhw", w2.double(), h) + b2.double()[None, :, None, None]
+    rm, rp = ref(mag, W[0], b[0], W[1], b[1]), ref(pha, W[2], b[2], W[3], b[3])
+    dm, dp = dev(mag).clone(), dev(pha).clone()
+    ops.spectral_mlp2(dm, dp, dev(W[0]), dev(b[0]), dev(W[1]), dev(b[1]), dev(W[2]), dev(b[2]), dev(W[3]), dev(b[3]), slope=0.1)
+    assert rel_rms(dm.cpu(), rm) < 5e-7 and rel_rms(dp.cpu(), rp) < 5e-7
+    cm = ops.conv1x1(ops.conv1x1(dev(mag), dev(W[0]), dev(b[0]), act=ACT_LEAKY), dev(W[1]), dev(b[1]))
+    cp = ops.conv1x1(ops.conv1x1(dev(pha), dev(W[2]), dev(b[2]), act=ACT_LEAKY), dev(W[3]), dev(b[3]))
+    assert rel_rms(dm.cpu(), cm.cpu()) < 1e-6 and rel_rms(dp.cpu(), cp.cpu()) < 1e-6
