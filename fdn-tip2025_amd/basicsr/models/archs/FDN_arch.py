@@ -238,11 +238,11 @@ class Fuse(nn.Module):
 
     def forward(self, enc, dnc, x_high=None, x_high_p=None, x_img=None):
         n = self.n_feat
-        x = ops.conv1x1([enc, dnc], _w(self.conv.weight), _w(self.conv.bias))
+        x = ops.conv1x1([enc, dnc], _w(self.conv.weight), _w(self.conv.bias), want_stats=True)      # (norm2 of att_channel reads them: no fdn_chan_stats pass)
         x = self.att_channel((x, x_high, x_high_p, x_img))[0]
         wf = self._c.get("w", [self.conv2.weight], lambda: self.conv2.weight.detach()[:n] + self.conv2.weight.detach()[n:])
         bf = self._c.get("b", [self.conv2.bias], lambda: self.conv2.bias.detach()[:n] + self.conv2.bias.detach()[n:])
-        return ops.conv1x1(x, wf, bf, cache=(self._c, "c2"))
+        return ops.conv1x1(x, wf, bf, cache=(self._c, "c2"), want_stats=True)                        # (norm1 of the next decoder block)
 
 
 class OverlapPatchEmbed(nn.Module):
