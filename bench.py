@@ -503,6 +503,8 @@ def main():
                     "720p': minutes of host time, off by default; the committed line is profiles/r05_cpu_720p.json)")
     ap.add_argument("--fdsa-full", action="store_true", help="A/B: route the level-1 FDSA sub-blocks through fdn_fdsa_full (one launch) instead of "
                     "fdn_fdsa_fused + fdn_fdsa_out (DESIGN.md section 4: built, correct, not the default)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short side measurements of BASELINE.json configs[2] (1080p B = 4 bf16 storage) "
+                    "and configs[4] (LPNet alone) that the default headline run appends as `other_configs`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -682,6 +684,54 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.dry_run:
         cpu = cpu_baseline(full_720p=a.cpu_720p)
 
+    # BASELINE.json names two more single-GPU configurations: they are measured here, briefly, in the same process and by the same protocol (captured
+    # graph, untimed warm-up, K steps between synchronisations), so that every run of the headline command records them too (VERDICT r4, row g)
+    other = None
+    if (rank == 0 and world == 1 and not a.dry_run and not a.no_other_configs and a.config == "fdn" and a.variant == "lolblur" and a.graph
+            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.narrow_pipe or a.unfused_mlps)):
+        from fdn_hip.pipeline import GraphedStep
+
+        def side(fn, xin, steps=3):
+            fn(xin)                                                    # capture + warm-up, untimed
+            fn(xin)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                fn(xin)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / steps
+        other = {}
+        try:
+            fdn_hip.set_storage_dtype("bf16")
+            x2 = make_input(4, 1080, 1920, dev, seed=2000)
+            ms2 = side(GraphedStep(net, lp, 1), x2)
+            other["configs[2]"] = {"workload": "FDN 1920x1080 (padded 1920x1088) batch=4, bf16 storage of block-internal activations, fp32 math", "value": 4e3 / ms2,
+                                   "unit": "images/s", "ms_per_step": ms2, "steps": 3, "dtype": "bf16"}
+            del x2
+        finally:
+            fdn_hip.set_storage_dtype("f32")
+        g4 = {}
+
+        def lp_graph(t):
+            if "g" not in g4:
+                g4["x"] = t.clone()
+                with torch.no_grad():
+                    for _ in range(2):
+                        lp(g4["x"])
+                    torch.cuda.synchronize()
+                    g4["g"] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g4["g"], capture_error_mode="thread_local"):
+                        g4["out"] = lp(g4["x"])
+            g4["x"].copy_(t)
+            g4["g"].replay()
+            return g4["out"]
+        ms4 = side(lp_graph, x, steps=20)
+        other["configs[4]"] = {"workload": f"LPNet_lolblur forward {a.width}x{a.height} (padded {W}x{H}) batch={B}, real weights", "value": B * 1e3 / ms4,
+                               "unit": "images/s", "ms_per_step": ms4, "steps": 20, "dtype": "f32"}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         imgs = world * B * a.steps
         ips = imgs / dt
@@ -714,7 +764,7 @@ def main():
             # B_alg = 7,256 elements per padded pixel x sizeof(elem) - 4 bytes in fp32, 2 in the bf16-storage configuration
             "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * (ips / world) / (PEAK_HBM_GBS * 1e9),
                            "mfma_f32_frac": F_ALG_PER_PX * P * (ips / world) / (PEAK_F32_MFMA_TF * 1e12)},
-            "roofline": roof, "top_kernels": top, "cpu_baseline": cpu,
+            "roofline": roof, "top_kernels": top, "cpu_baseline": cpu, "other_configs": other,
         }
         if a.config == "lpnet":
             line["whole_path"] = None                               # SURVEY 8(d)'s F_alg / B_alg are the LPNet -> FDN path's
