@@ -42,7 +42,7 @@ def call(l, k):
     if k == "gate":
         return l.fdn_dwconv_gate(P(h), P(wg), P(out_h), B, Hd, H, W, 0, 0, st_())
     if k == "tail":
-        return l.fdn_ffn_tail(P(h), P(wg), P(wo), P(x), P(out_c), P(st_out), B, Hd, C, H, W, 0, 1 if lvl == 1 else 0, st_())
+        return l.fdn_ffn_tail(P(h), P(wg), P(wo), P(x), P(out_c), P(st_out), B, Hd, C, H, W, 0, 1, st_())
     if k == "core":
         return l.fdn_fdsa_core(P(hid), P(dw), P(fw), P(out_4e), B, E, H, W, st_())
     if k == "out":
