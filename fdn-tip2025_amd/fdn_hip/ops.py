@@ -585,7 +585,8 @@ def scale_batch_(x, ratio):
     return x
 
 
-SPECTRAL_MLP_C = (12, 24, 48)      # widths fdn_spectral_mlp2 has a form for (MAR's three levels, both models)
+SPECTRAL_MLP_C = (12, 24)          # widths the mirror sends to fdn_spectral_mlp2 (MAR's levels 1-2).  C = 48 exists in the library but is NOT used:
+                                   # its 9,216 weight reads per bin make it 0.34 ms per block against 0.17 ms for the four MFMA convs (profiles/r05_f_summary.txt)
 SPECTRAL_MLP_FUSED = True           # False: the four fdn_conv1x1 launches per block instead (A/B runs: bench.py --unfused-mlps)
 
 
