@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256) void convT_kernel(const float* __restrict__ x,
 template <int OCB_>
 __global__ __launch_bounds__(256) void convT_quad_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, int Cin, int H, int W, int Cout, int act) {
+    // a thread takes TWO horizontally adjacent input pixels (ix0, ix0 + 1; W is even on this path): a 3 x 4 input window, two output quads, and
+    // every weight row read from LDS feeds two FMAs - with one pixel per thread the kernel was bound by its 48 broadcast reads of 16 bytes per input
+    // channel (the CU's one LDS pipe returns 1 KB per wave and read: 1.07 ms for MAR's two up-convs where the vector work needs ~0.3 ms)
     static_assert(OCB_ % 4 == 0, "weight rows are read as 16-byte words");
     extern __shared__ __attribute__((aligned(16))) float wl[];          // [ci][tap = ky * 4 + kx][OCB_]
     unsigned bx, by, bz;
@@ -220,31 +223,34 @@ __global__ __launch_bounds__(256) void convT_quad_kernel(const float* __restrict
     }
     __syncthreads();
     const long hw = (long)H * W;
-    const long ip = (long)bx * 256 + threadIdx.x;
-    const bool live = ip < hw;
-    const int iy = live ? (int)(ip / W) : 0, ix = live ? (int)(ip - (long)iy * W) : 0;
-    // the 3 x 3 window: offsets relative to the plane, 0 and a cleared flag outside the image
-    int off[9];
+    const int W2 = W >> 1;
+    const long ip = (long)bx * 256 + threadIdx.x;                          // pixel PAIR index
+    const bool live = ip < (long)H * W2;
+    const int iy = live ? (int)(ip / W2) : 0, ix0 = live ? 2 * (int)(ip - (long)iy * W2) : 0;
+    // the 3 x 4 window: offsets relative to the plane, 0 and a cleared flag outside the image
+    int off[12];
     unsigned ok = 0;
 #pragma unroll
-    for (int d = 0; d < 9; ++d) {
-        const int y = iy - 1 + d / 3, xx = ix - 1 + d % 3;
+    for (int d = 0; d < 12; ++d) {
+        const int y = iy - 1 + d / 4, xx = ix0 - 1 + d % 4;
         const bool v = live && y >= 0 && y < H && xx >= 0 && xx < W;
         off[d] = v ? y * W + xx : 0;
         ok |= (v ? 1u : 0u) << d;
     }
-    float acc[4][OCB_];                                                    // [2 py + px][channel]
+    float acc[2][4][OCB_];                                                 // [pixel of the pair][2 py + px][channel]
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int o = 0; o < OCB_; ++o) acc[q][o] = 0.f;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = 0; o < OCB_; ++o) acc[u][q][o] = 0.f;
     const float* xc = x + (long)b * Cin * hw;
     for (int ci = 0; ci < Cin; ++ci, xc += hw) {
-        float v[9];
+        float v[12];
 #pragma unroll
-        for (int d = 0; d < 9; ++d) v[d] = xc[off[d]];
+        for (int d = 0; d < 12; ++d) v[d] = xc[off[d]];
 #pragma unroll
-        for (int d = 0; d < 9; ++d) v[d] = ((ok >> d) & 1u) ? v[d] : 0.f;
+        for (int d = 0; d < 12; ++d) v[d] = ((ok >> d) & 1u) ? v[d] : 0.f;
         const float* wc = wl + ci * 16 * OCB_;
 #pragma unroll
         for (int py = 0; py < 2; ++py)
@@ -256,10 +262,14 @@ __global__ __launch_bounds__(256) void convT_quad_kernel(const float* __restrict
                     const int ky = ky0 + 2 * (j >> 1), kx = kx0 + 2 * (j & 1);
                     // oy = 2 iy' - 1 + ky  =>  iy' = iy + (py + 1 - ky) / 2: window row 1 + (py + 1 - ky) / 2 (exact: the difference is even)
                     const int wy = 1 + (py + 1 - ky) / 2, wx = 1 + (px + 1 - kx) / 2;
-                    const float vv = v[wy * 3 + wx];
                     const float* wp = wc + (ky * 4 + kx) * OCB_;
+                    const float va = v[wy * 4 + wx], vb = v[wy * 4 + wx + 1];
 #pragma unroll
-                    for (int o = 0; o < OCB_; ++o) acc[2 * py + px][o] = fmaf(vv, wp[o], acc[2 * py + px][o]);
+                    for (int o = 0; o < OCB_; ++o) {
+                        const float ww = wp[o];
+                        acc[0][2 * py + px][o] = fmaf(va, ww, acc[0][2 * py + px][o]);
+                        acc[1][2 * py + px][o] = fmaf(vb, ww, acc[1][2 * py + px][o]);
+                    }
                 }
             }
     }
@@ -270,9 +280,11 @@ __global__ __launch_bounds__(256) void convT_quad_kernel(const float* __restrict
     for (int o = 0; o < OCB_; ++o) {
         if (o < nvalid) {                                                  // (no `break`: the accumulators keep static register indices)
             const float bb = bias ? bias[oc0 + o] : 0.f;
-            float* op = out + ((long)b * Cout + oc0 + o) * OP + (long)(2 * iy) * OW + 2 * ix;
-            *reinterpret_cast<float2*>(op) = make_float2(apply_act(acc[0][o] + bb, act), apply_act(acc[1][o] + bb, act));
-            *reinterpret_cast<float2*>(op + OW) = make_float2(apply_act(acc[2][o] + bb, act), apply_act(acc[3][o] + bb, act));
+            float* op = out + ((long)b * Cout + oc0 + o) * OP + (long)(2 * iy) * OW + 2 * ix0;
+            *reinterpret_cast<float4*>(op) = make_float4(apply_act(acc[0][0][o] + bb, act), apply_act(acc[0][1][o] + bb, act),
+                                                         apply_act(acc[1][0][o] + bb, act), apply_act(acc[1][1][o] + bb, act));
+            *reinterpret_cast<float4*>(op + OW) = make_float4(apply_act(acc[0][2][o] + bb, act), apply_act(acc[0][3][o] + bb, act),
+                                                              apply_act(acc[1][2][o] + bb, act), apply_act(acc[1][3][o] + bb, act));
         }
     }
 }
@@ -580,8 +592,8 @@ extern "C" int fdn_conv_transpose4x4s2(const float* x, const float* w, const flo
                                        int W, int Cout, int act, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && w && out && B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (Cout >= 12 && (size_t)Cin * 16 * 12 * sizeof(float) <= 48 * 1024 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {      // quad form, 12 channels per block
-        hipLaunchKernelGGL(convT_quad_kernel<12>, dim3(cdiv((long)H * W, 256), cdiv(Cout, 12), B), dim3(256), (size_t)Cin * 16 * 12 * sizeof(float), s,
+    if (Cout >= 12 && W % 2 == 0 && (size_t)Cin * 16 * 12 * sizeof(float) <= 48 * 1024 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {      // quad form, 12 channels per block
+        hipLaunchKernelGGL(convT_quad_kernel<12>, dim3(cdiv((long)H * (W / 2), 256), cdiv(Cout, 12), B), dim3(256), (size_t)Cin * 16 * 12 * sizeof(float), s,
                            x, w, bias, out, Cin, H, W, Cout, act);
         return fdn_launch_status();
     }
