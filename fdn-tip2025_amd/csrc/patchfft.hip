@@ -672,23 +672,26 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         for (int j = 0; j < (AW_AHEAD ? KS : 1); ++j) aw[j] = wp[j * 64];
     };
     float st_w = 0.f, st_w1 = 0.f, st_f0 = 0.f, st_f1 = 0.f;
+    // (round 5: descriptor loads with 32-bit offsets - as plain pointers the lane-invariant halves of the 64-bit addresses were hoisted out of the chunk
+    //  loop and, at C = 64, spilled: five scratch reloads per chunk, each waiting for every load AND store in flight - scratch shares vmcnt)
+    const rsrc_t rdw = mk_rsrc(a.dww, (unsigned)(4 * E * 9) * 4u), rfw = mk_rsrc(a.fftw, (unsigned)(E * 40) * 4u);
     auto stage_fetch = [&](int ch) {
         auto tap_of = [&](int i) {                                      // element i < 288: row m = kind * 8 + channel, tap i % 9
             if constexpr (CELLS) {                                      // ... or (channel, tap, kind)
                 const int cl = i / 36, rem = i - cl * 36;
                 const int ew = ch * FEG + cl;
-                return a.dww[(long)((rem & 3) * E + (ew < E ? ew : E - 1)) * 9 + (rem >> 2)];
+                return bload(rdw, (unsigned)(((rem & 3) * E + (ew < E ? ew : E - 1)) * 9 + (rem >> 2)) * 4u, 0);
             }
             const int m = i / 9, tap = i - m * 9;
             const int ew = ch * FEG + (m & 7);
-            return a.dww[(long)((m >> 3) * E + (ew < E ? ew : E - 1)) * 9 + tap];
+            return bload(rdw, (unsigned)(((m >> 3) * E + (ew < E ? ew : E - 1)) * 9 + tap) * 4u, 0);
         };
         st_w = tap_of(tid);
         st_w1 = tid < 32 ? tap_of(tid + 256) : 0.f;
         const int c0 = tid / 40, c1 = (tid + 256) / 40;                 // gains: 320 values
         const int e0_ = ch * FEG + c0, e1_ = ch * FEG + c1;
-        st_f0 = a.fftw[(e0_ < E ? e0_ : E - 1) * 40 + (tid - c0 * 40)];
-        st_f1 = (tid < 64) ? a.fftw[(e1_ < E ? e1_ : E - 1) * 40 + (tid + 256 - c1 * 40)] : 0.f;
+        st_f0 = bload(rfw, (unsigned)((e0_ < E ? e0_ : E - 1) * 40 + (tid - c0 * 40)) * 4u, 0);
+        st_f1 = (tid < 64) ? bload(rfw, (unsigned)((e1_ < E ? e1_ : E - 1) * 40 + (tid + 256 - c1 * 40)) * 4u, 0) : 0.f;
     };
     auto stage_store = [&]() {
         wks[tid] = st_w;
