@@ -108,7 +108,7 @@ class FDSA(nn.Module):
         y = ops.fdsa_out(o, _w(self.project_out.weight), gam, bet, res=res, want_stats=res is not None)   # levels 1, 2
         if y is not None:
             return y
-        stats = ops.chan_stats(o[:, :3 * e], groups=3)
+        stats = None if ops.GEMM_OWN_STATS else ops.chan_stats(o[:, :3 * e], groups=3)      # None: the GEMM takes them in a pass over its tile
         return ops.conv1x1(o[:, :3 * e], _w(self.project_out.weight), ln3_gate=(stats, gam, bet, o[:, 3 * e:]), res=res,
                            want_stats=res is not None, cache=(self._c, "po"))
 
@@ -181,7 +181,7 @@ class FCAFFN(nn.Module):
         elif xi.shape[1] >= ops.FCAFFN_PACKED_MIN_C and fdn_hip.matrix_pipe() == "bf16":          # level 3: the same sub-block on the split-bf16 GEMM, one launch
             srcs = [self.project_in.weight, self.conv1_mul.weight, self.conv3_mul.weight, self.conv1_add.weight, self.conv3_add.weight]
             wpk = self._c.get("fcpk", srcs, lambda: ops.fcaffn_in_pack(*[_w(p) for p in srcs]))
-            t = ops.fcaffn_in_packed(xi, ops.chan_stats(xi), xn, x_img, wpk, gam, bet, x1_ln=ln)
+            t = ops.fcaffn_in_packed(xi, None if ops.GEMM_OWN_STATS else ops.chan_stats(xi), xn, x_img, wpk, gam, bet, x1_ln=ln)
         else:
             stats = ops.chan_stats(xi)
             mul, add = ops.img_mod_maps(x_img, _w(self.conv1_mul.weight), _w(self.conv3_mul.weight),

@@ -1466,7 +1466,10 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
     FDN_CHECK_ARG(d.kseg[0] + d.kseg[1] + d.kseg[2] == d.K);
     FDN_CHECK_ARG(d.kseg[1] == 0 || d.x[1]);
     FDN_CHECK_ARG(d.kseg[2] == 0 || d.x[2]);
-    if (d.pro != FDN_PRO_NONE) FDN_CHECK_ARG(d.stats);
+    // stats == NULL with a LayerNorm prologue: the K-streaming split-bf16 kernel takes the statistics itself (LN3_GATE / LN_MULADD with packed
+    // weights on a deep shape); every other kernel wants them from fdn_chan_stats or a producer's epilogue
+    const bool own_stats = d.pro != FDN_PRO_NONE && !d.stats;
+    if (own_stats) FDN_CHECK_ARG(d.pro == FDN_PRO_LN3_GATE || d.pro == FDN_PRO_LN_MULADD);
     if (d.pro >= FDN_PRO_LN3_GATE) FDN_CHECK_ARG(d.gamma && d.beta);
     if (d.pro == FDN_PRO_LN3_GATE) FDN_CHECK_ARG(d.xb && d.ln_group * 3 == d.K && d.kseg[0] == d.K);
     if (d.pro == FDN_PRO_LN_MULADD) FDN_CHECK_ARG(d.xb);
@@ -1487,7 +1490,7 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
     //   x_bf16  : the project_out convs (narrow TAIL form / K-streaming form), fp32 result;
     //   out_bf16: the project_in convs (small-K form, plain or LayerNorm prologue), fp32 input.
     if (d.x_bf16 || d.out_bf16) {
-        if (d.x_bf16 && d.out_bf16) return FDN_ERR_UNSUPPORTED;
+        if ((d.x_bf16 && d.out_bf16) || own_stats) return FDN_ERR_UNSUPPORTED;
         if (d.x_bf16) {
             if (kstream_vec_ok(d)) {
                 const int tiles = (d.N + 31) / 32;
@@ -1519,6 +1522,7 @@ extern "C" int fdn_conv1x1(const fdn_conv1x1_desc* dp, fdn_stream_t stream) {
         const int rc = fdn_gemm_split(d, s);            // level 3 with packed weights: fp32 on the bf16 matrix pipe (gemm_split.hip)
         if (rc != FDN_ERR_UNSUPPORTED) return rc;
     }
+    if (own_stats) return FDN_ERR_UNSUPPORTED;
     {
         const int rc = fdn_gemm_tile(d, s);             // 459 -> 128 (LN3 * v_value), 345 -> 128, 128 -> 128 at level 3
         if (rc != FDN_ERR_UNSUPPORTED) return rc;

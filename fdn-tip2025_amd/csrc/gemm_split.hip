@@ -90,12 +90,70 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
     const rsrc_t rv = mk_rsrc((TRI || LNM) ? d.xb + (long)b * d.xbbs : d.x[0], TRI ? (unsigned)E * P4 : LNM ? (unsigned)K * P4 : 0u);
     const fdn_u32x4* wsrc = reinterpret_cast<const fdn_u32x4*>(d.wpk) + (long)nt * nch * BLK;
     float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};                  // (x - mean) * rstd = x * sa + sb
-    if (TRI || LN || LNM) {
+    if ((TRI || LN || LNM) && d.stats) {
 #pragma unroll
         for (int g = 0; g < (TRI ? 3 : 1); ++g) {
             const float* sp = d.stats + ((long)b * (TRI ? 3 : 1) + g) * 2 * P;
             sa[g] = sp[P + pix];
             sb[g] = -sp[pix] * sa[g];
+        }
+    }
+    if constexpr (TRI || LNM) {
+        // (round 5) stats == NULL: the LayerNorm statistics of this pixel tile are taken HERE, in a pass over the tile's K planes before the
+        // product (the fdn_chan_stats launch and its HBM read of the 3E / K planes go away; the product's own read of the tile then comes from
+        // L2 / the Infinity Cache).  Shifted sums around the group's first channel, as fdn_chan_stats does (norm.hip); the two k-step halves of a
+        // pixel (threads xp and xp + 128) each take their own channels and meet in LDS.
+        if (!d.stats) {
+            constexpr int G = TRI ? 3 : 1;
+            const int Eg = TRI ? E : K;                                       // channels per LayerNorm group
+            float x0[G], s[G], ss[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                x0[g] = bload(rx, pix * 4u, (unsigned)(g * Eg) * P4);
+                s[g] = ss[g] = 0.f;
+            }
+            constexpr int PER = TRI ? 5 : 16, STEP = TRI ? TRI_E : KC;        // channels per thread and per chunk
+            const int nfull = Eg / STEP;                                      // chunks whose channels all exist
+#pragma unroll 2
+            for (int c = 0; c < nfull; ++c) {
+                float v[G][PER];
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) v[g][j] = bload(rx, pix * 4u, (unsigned)(g * Eg + c * STEP + PER * hh + j) * P4);
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float dl = v[g][j] - x0[g];
+                        s[g] += dl;
+                        ss[g] = fmaf(dl, dl, ss[g]);
+                    }
+            }
+            for (int e = nfull * STEP + PER * hh; e < min(Eg, nfull * STEP + PER * hh + PER); ++e)       // the ragged last chunk (uniform bounds)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float dl = bload(rx, pix * 4u, (unsigned)(g * Eg + e) * P4) - x0[g];
+                    s[g] += dl;
+                    ss[g] = fmaf(dl, dl, ss[g]);
+                }
+            float* sx = reinterpret_cast<float*>(Xs);                         // [half][group][s | ss][pixel]: Xs is not in use yet
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                sx[((hh * G + g) * 2 + 0) * TP + xp] = s[g];
+                sx[((hh * G + g) * 2 + 1) * TP + xp] = ss[g];
+            }
+            __syncthreads();
+            const float inv = 1.0f / (float)Eg;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float st = sx[((0 * G + g) * 2 + 0) * TP + xp] + sx[((1 * G + g) * 2 + 0) * TP + xp];
+                const float sst = sx[((0 * G + g) * 2 + 1) * TP + xp] + sx[((1 * G + g) * 2 + 1) * TP + xp];
+                const float md = st * inv;                                    // mean - x0
+                sa[g] = 1.0f / sqrtf(fmaxf(sst * inv - md * md, 0.f) + 1e-5f);
+                sb[g] = -(x0[g] + md) * sa[g];
+            }
+            __syncthreads();                                                  // Xs is staged next
         }
     }
     const bool x1ln = FC && a.xb_stats != nullptr;                            // uniform
@@ -747,7 +805,7 @@ extern "C" int fdn_fcaffn_in_pack(const float* w, const float* w1_mul, const flo
 extern "C" int fdn_fcaffn_in_packed(const float* xi, const float* stats_xi, const float* x1, const float* stats1, const float* gamma1,
                                     const float* beta1, const float* img, const void* wpk, const float* gamma, const float* beta, float* out,
                                     int B, int C, int H, int W, fdn_stream_t stream) {
-    FDN_CHECK_ARG(xi && stats_xi && x1 && img && wpk && gamma && beta && out && B > 0 && C > 0 && H > 0 && W > 0);
+    FDN_CHECK_ARG(xi && x1 && img && wpk && gamma && beta && out && B > 0 && C > 0 && H > 0 && W > 0);      // stats_xi NULL: taken in the kernel
     FDN_CHECK_ARG((stats1 && gamma1 && beta1) || (!stats1 && !gamma1 && !beta1));
     const long P = (long)H * W;
     if (fdn_matrix_pipe_f32()) return FDN_ERR_UNSUPPORTED;

@@ -121,6 +121,8 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
 
     xs: tensor or list of <=3 tensors concatenated along channels.  w: [N, K] or [N, K, 1, 1].
     ln=(stats, gamma, beta) | ln3_gate=(stats, gamma[3E], beta[3E], vv) | ln_muladd=(stats, gamma, beta, x1)
+    (ln3_gate / ln_muladd: stats=None lets the kernel take the statistics itself - the K-streaming split-bf16 kernel does, in a pass over
+    its pixel tile; for every other shape the fdn_chan_stats launch happens here)
     res: residual added after act | muladd=(mul, add).
     cache=(WeightCache, name): where the derived operands are kept - the LayerNorm-folded weights of `ln` (else they are rebuilt
     per call) and, for the deep shapes (K, N >= 96: level 3), the packed split-bf16 weights that put the GEMM on the bf16
@@ -184,10 +186,19 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
     if want_stats and N <= 160:
         stats = torch.empty((B, 1, 2, P), device=out.device, dtype=torch.float32)
         d.stats_out = _flat(stats, "stats_out")
-    check(lib().fdn_conv1x1(ctypes.byref(d), stream()), "fdn_conv1x1")
+    rc = lib().fdn_conv1x1(ctypes.byref(d), stream())
+    if rc == 4 and d.pro in (PRO_LN3_GATE, PRO_LN_MULADD) and not d.stats:      # FDN_ERR_UNSUPPORTED: no kernel of this shape takes the statistics itself
+        x0 = xs[0]
+        auto = chan_stats(x0, groups=3) if ln3_gate is not None else chan_stats(x0)
+        d.stats = _flat(auto, "stats")
+        rc = lib().fdn_conv1x1(ctypes.byref(d), stream())
+    check(rc, "fdn_conv1x1")
     if want_stats:
         out._fdn_stats = stats if stats is not None else chan_stats(out)   # LayerNorm statistics travel with the tensor
     return out
+
+
+GEMM_OWN_STATS = True       # the level-3 LN3 / FCAFFN GEMMs take their LayerNorm statistics in-kernel (False: an fdn_chan_stats launch in front; A/B runs)
 
 
 def stats_of(x):
@@ -402,7 +413,8 @@ def fcaffn_in_pack(w, w1_mul, w3_mul, w1_add, w3_add):
 
 
 def fcaffn_in_packed(xi, stats_xi, x1, img, wpk, gamma, beta, x1_ln=None):
-    """fcaffn_in for C >= FCAFFN_PACKED_MIN_C (level 3): one launch on the split-bf16 GEMM; stats_xi = chan_stats(xi)."""
+    """fcaffn_in for C >= FCAFFN_PACKED_MIN_C (level 3): one launch on the split-bf16 GEMM; stats_xi = chan_stats(xi), or None: the kernel
+    takes the statistics of xi itself."""
     B, C, H, W = xi.shape
     out = torch.empty_like(xi)
     st1, g1, b1 = x1_ln if x1_ln is not None else (None, None, None)

@@ -200,6 +200,8 @@ def test_fcaffn_in_packed_equals_unfused(A, C, H, W, B):
     assert rel_rms(got.cpu(), ref.cpu()) < 5e-7
     g1, b1 = dev(_rnd(C, seed=11) * 0.2 + 1.0), dev(_rnd(C, seed=12) * 0.1)
     raw = dev(_rnd(B, C, H, W, seed=13) * 2.0 + 0.5)
+    own = ops.fcaffn_in_packed(xi, None, x1, img, wpk, g, b_)                  # (round 5) the kernel takes the statistics of xi itself
+    assert (own - got).abs().max().item() <= 2e-6 * max(1.0, got.abs().max().item())
     via_ln = ops.fcaffn_in_packed(xi, st, raw, img, wpk, g, b_, x1_ln=(ops.chan_stats(raw), g1, b1))
     via_copy = ops.fcaffn_in_packed(xi, st, ops.layernorm_chan(raw, g1, b1), img, wpk, g, b_)
     assert (via_ln - via_copy).abs().max().item() / via_copy.abs().max().item() < 4e-6

@@ -416,6 +416,44 @@ def test_conv1x1_split_bf16_kernel(A, K, N, H, W, pro, epi):
     assert torch.equal(again, got)
 
 
+@pytest.mark.parametrize("K,N,H,W,pro", [(459, 128, 23, 41, "ln3"), (345, 128, 8, 17, "ln3"), (300, 128, 9, 21, "ln3"), (459, 128, 184, 320, "ln3"),
+                                        (128, 128, 23, 40, "muladd"), (100, 130, 9, 13, "muladd"), (114, 32, 24, 40, "ln3")])
+def test_gemm_takes_its_own_layernorm_statistics(A, K, N, H, W, pro):
+    """stats=None (round 5): the K-streaming split-bf16 kernel takes the LayerNorm statistics of its pixel tile itself, in a pass before the
+    product (no fdn_chan_stats launch in front of the level-3 project_out / FCAFFN GEMMs, FDN_arch.py:633-639, :420).  Held to the bound of the
+    route with the launch, against float64, and to rounding-level agreement with it; a shape no such kernel covers ((114, 32): level 1 without
+    the one-launch tail) falls back to the launch inside ops.conv1x1."""
+    from fdn_hip import ops
+    B = 2
+    x, w = _rnd(B, K, H, W, seed=1) * 1.5 + 0.3, _rnd(N, K, seed=2) / K ** 0.5
+    xd = x.double()
+    g, b = _rnd(K, seed=4), _rnd(K, seed=5)
+    if pro == "ln3":
+        E = K // 3
+        vv = _rnd(B, E, H, W, seed=6)
+        xin = torch.cat([O.ln_chan(xd[:, i * E:(i + 1) * E], g[i * E:(i + 1) * E].double(), b[i * E:(i + 1) * E].double()) * vv.double()
+                         for i in range(3)], 1)
+        full = dev(torch.cat([x, vv], 1))
+        xs = full[:, :K]
+        mk = lambda st: {"ln3_gate": (st, dev(g), dev(b), full[:, K:])}
+        given = ops.chan_stats(xs, groups=3)
+    else:
+        x1 = _rnd(B, K, H, W, seed=6)
+        xin = O.ln_chan(xd, g.double(), b.double()) * x1.double() + x1.double()
+        xs = dev(x)
+        mk = lambda st: {"ln_muladd": (st, dev(g), dev(b), dev(x1))}
+        given = ops.chan_stats(xs)
+    r = _rnd(B, N, H, W, seed=7)
+    ref = torch.nn.functional.conv2d(xin, w.double().view(N, K, 1, 1)) + r.double()
+    wc = ops.WeightCache()
+    own = ops.conv1x1(xs, dev(w), res=dev(r), cache=(wc, "t"), **mk(None))
+    launched = ops.conv1x1(xs, dev(w), res=dev(r), cache=(wc, "t"), **mk(given))
+    e_own, e_l = rel_rms(own.cpu(), ref), rel_rms(launched.cpu(), ref)
+    assert e_own < 2e-6 and e_own < 1.5 * e_l + 2e-8, (e_own, e_l)
+    assert rel_rms(own.cpu(), launched.cpu().double()) < 5e-7
+    assert torch.equal(own, ops.conv1x1(xs, dev(w), res=dev(r), cache=(wc, "t"), **mk(None)))
+
+
 @pytest.mark.parametrize("C,N,H,W", [(86, 32, 24, 40), (345, 128, 16, 24), (64, 64, 46, 40), (43, 16, 8, 35), (172, 64, 40, 72),
                                      (129, 48, 16, 136), (32, 32, 736, 1280)])
 def test_ffn_tail_fused_equals_reference(A, C, N, H, W):
