@@ -63,7 +63,9 @@ long fdn_bf16_mfma_launches(void);
  * w = W * diag(gamma), bias = W * beta (+ bias) - gamma / beta are ignored) | LN3_GATE (x = [o1|o2|o3] each
  * ln_group channels, three LayerNorms with gamma / beta [K], times xb = v_value[ln_group]) |
  * LN_MULADD (LN(x)*xb + xb, gamma / beta [K]).
- * stats: [B][G][2][P] = (mean, rstd) from fdn_chan_stats, G = 3 for LN3_GATE else 1.
+ * stats: [B][G][2][P] = (mean, rstd) from fdn_chan_stats, G = 3 for LN3_GATE else 1.  ABI 13: NULL with LN3_GATE / LN_MULADD = the kernel
+ * takes the statistics of its pixel tile itself - only the K-streaming split-bf16 kernel does (packed weights, K and N >= 96); every
+ * other shape returns FDN_ERR_UNSUPPORTED and wants the fdn_chan_stats launch.
  * epi: NONE | RES (+res) | MULADD (*mul + add).  act is applied before epi. */
 typedef struct fdn_conv1x1_desc {
     const float* x[3];
@@ -203,7 +205,7 @@ int fdn_fcaffn_in(const float* xi, const float* x1, const float* stats1, const f
  * w3[c][tap] * w1[c][ch] - replaces fdn_layernorm_chan(x1) + fdn_img_mod_maps(img) + fdn_conv1x1(FDN_PRO_LN_MULADD, FDN_EPI_MULADD)
  * (FDN_arch.py:419-423, :675), whose 3 C planes of intermediates are never written.
  * fdn_fcaffn_in_pack: w [C][C], w1_* [C][3], w3_* [C][9] -> wpk (fdn_fcaffn_in_pack_bytes(C) bytes), once per weight set.
- * fdn_fcaffn_in_packed: stats_xi [B][2][H*W] from fdn_chan_stats(xi); stats1 / gamma1 / beta1 as in fdn_fcaffn_in (all three or
+ * fdn_fcaffn_in_packed: stats_xi [B][2][H*W] from fdn_chan_stats(xi), or (ABI 13) NULL: taken in the kernel; stats1 / gamma1 / beta1 as in fdn_fcaffn_in (all three or
  *   none).  C < 96 returns FDN_ERR_UNSUPPORTED (use fdn_fcaffn_in). */
 long fdn_fcaffn_in_pack_bytes(int C);
 int fdn_fcaffn_in_pack(const float* w, const float* w1_mul, const float* w3_mul, const float* w1_add, const float* w3_add, int C,
