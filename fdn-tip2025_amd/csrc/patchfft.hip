@@ -676,6 +676,17 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     //  loop and, at C = 64, spilled: five scratch reloads per chunk, each waiting for every load AND store in flight - scratch shares vmcnt)
     const rsrc_t rdw = mk_rsrc(a.dww, (unsigned)(4 * E * 9) * 4u), rfw = mk_rsrc(a.fftw, (unsigned)(E * 40) * 4u);
     auto stage_fetch = [&](int ch) {
+        // (C = 64: the lane-invariant pieces of the indices below - tid / 9, tid / 40 and their remainders - were hoisted out of the chunk loop and
+        //  spilled: 11 scratch reloads per chunk in four dependent groups, each waiting for vmcnt(0).  Behind an opaque copy of tid they are
+        //  recomputed per chunk instead, ~30 vector instructions.  Together with the strips' LDS offsets (mfma_phase), wave 3's coordinates and the
+        //  one-output-at-a-time recombination of the column phase: 19 -> 0 spilled registers, level 2 1.371 -> 1.327 ms, interleaved, bit-identical
+        //  (profiles/r05_l_fused64_ab.txt).  The same treatment of stage_store's two addresses costs 10 %, and C <= 48 keeps the hoisted form:
+        //  this change alone cost the C = 32 kernel 2.7 %)
+        const int tid_o = tid;
+        const int tid = [&] {
+            if constexpr (KST >= 4) { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+            else return tid_o;
+        }();
         auto tap_of = [&](int i) {                                      // element i < 288: row m = kind * 8 + channel, tap i % 9
             if constexpr (CELLS) {                                      // ... or (channel, tap, kind)
                 const int cl = i / 36, rem = i - cl * 36;
@@ -700,13 +711,26 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         if (tid < 64) fgs[tid + 256] = st_f1;
     };
     // (C >= 48: the strips alone take 108 / 144 registers, so the A operands are not held in registers at all - each k-step reads its
-    //  three fragments from L1 / L2: 1.43 ms against 1.53-1.56 ms at level 2 for the variants that hold them in registers.  C = 64 STILL
-    //  spills 20 registers - loop-invariant coordinates stored once and reloaded by ~12 scratch loads per chunk, profiles/r04_spills.txt;
-    //  C <= 48 does not spill)
+    //  three fragments from L1 / L2: 1.43 ms against 1.53-1.56 ms at level 2 for the variants that hold them in registers.  No width spills
+    //  since round 5 (C = 64 spilled 20 registers through round 4, profiles/r04_spills.txt))
     // ---- to_hidden of one chunk on the matrix cores: D[32 rows][32 halo pixels] per strip -> LDS planes (0 outside the image: the
     // strip, its statistics and `xone` all read 0 there)
     auto mfma_phase = [&](int ch) __attribute__((always_inline)) {
         const fdn_u32x4* wp_ = reinterpret_cast<const fdn_u32x4*>(a.wpk) + ((long)ch * KS) * 64 + lane;      // (!AW_AHEAD: operands straight from L1 / L2)
+        int po[3];
+        if constexpr (KST >= 4) {           // (C = 64: the LDS offsets of the strips' pixels are rebuilt here instead of living across the chunk)
+            int t = threadIdx.x;
+            asm volatile("" : "+v"(t));
+#pragma unroll
+            for (int si = 0; si < 3; ++si) {
+                const int p = ((t >> 6) + 4 * si) * 32 + (t & 31);
+                const int r = p / FHW, c = p - r * FHW;
+                po[si] = p < FHP ? r * FRS + c : FHW;
+            }
+        } else {
+#pragma unroll
+            for (int si = 0; si < 3; ++si) po[si] = pixoff[si];
+        }
         // (round 5, measured: issuing the three strips' chains in turn - three accumulators - changes nothing, 2.315 against 2.288 ms: the phase is not
         //  bound by the latency of a dependent chain)
 #pragma unroll
@@ -728,10 +752,10 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
                 if constexpr (CELLS) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        reinterpret_cast<f32x4*>(hid)[(2 * g + kh) * FPL + pixoff[si]] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                        reinterpret_cast<f32x4*>(hid)[(2 * g + kh) * FPL + po[si]] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) hid[((r & 3) * 8 + 2 * (r >> 2) + kh) * FPL + pixoff[si]] = acc[r];   // plane = kind * 8 + channel
+                    for (int r = 0; r < 16; ++r) hid[((r & 3) * 8 + 2 * (r >> 2) + kh) * FPL + po[si]] = acc[r];   // plane = kind * 8 + channel
                 }
             }
         }
@@ -841,6 +865,42 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
             if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             fft8<false>(v);
             if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
+            constexpr float sc = 1.0f / 64.0f;   // norm='backward'
+            if constexpr (KST >= 4) {
+                // C = 64: 144 registers hold the strips, so the recombination keeps (u, |qk|, |qk| / |v|, |v|, v1) per bin - 56 registers where
+                // o1, o2, o3 take 48 on top of q, k, v - and the three outputs are formed, transformed and parked one after the other (the same
+                // operations on the same values: bit-identical)
+                float2 u_[8], v1_[8];
+                float qka_[8], g_[8], va_[8];
+#pragma unroll
+                for (int ky = 0; ky < 8; ++ky) {
+                    const float f = fg[ky];
+                    const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));
+                    float2 qk = cmul(q[ky], k[ky]);
+                    qk = make_float2(rd1(qk.x), rd1(qk.y));
+                    const float qk2 = qk.x * qk.x + qk.y * qk.y, v2 = v1.x * v1.x + v1.y * v1.y;
+                    const float qka = qk2 * rsq(qk2);
+                    const float iv = rsq(v2), va = v2 * iv;
+                    const float2 qr = make_float2(rd1(q[ky].x), rd1(q[ky].y));
+                    const float2 kr = make_float2(rd1(k[ky].x), rd1(k[ky].y));
+                    const float nq = rsq(qr.x * qr.x + qr.y * qr.y), nk = rsq(kr.x * kr.x + kr.y * kr.y);
+                    u_[ky] = cmulc(make_float2(qr.x * nq, qr.y * nq), make_float2(kr.x * nk, kr.y * nk));
+                    v1_[ky] = v1; qka_[ky] = qka; g_[ky] = qka * iv; va_[ky] = va;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    float2 o[8];
+#pragma unroll
+                    for (int ky = 0; ky < 8; ++ky)
+                        o[ky] = t == 0 ? make_float2(va_[ky] * u_[ky].x, va_[ky] * u_[ky].y)
+                              : t == 1 ? make_float2(g_[ky] * v1_[ky].x, g_[ky] * v1_[ky].y) : make_float2(qka_[ky] * u_[ky].x, qka_[ky] * u_[ky].y);
+                    fft8<true>(o);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) S[(t * NP + pj) * PS + kx * KXS + i] = make_float2(o[i].x * sc, o[i].y * sc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             float2 o1[8], o2[8], o3[8];
 #pragma unroll
             for (int ky = 0; ky < 8; ++ky) {
@@ -866,21 +926,24 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
             fft8<true>(o2);
             if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             fft8<true>(o3);
-            constexpr float sc = 1.0f / 64.0f;   // norm='backward'
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 S[(0 * NP + pj) * PS + kx * KXS + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
                 S[(1 * NP + pj) * PS + kx * KXS + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
                 S[(2 * NP + pj) * PS + kx * KXS + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
             }
+            }
         } else if (!CELLS && wave == 3) {
             // the 160 column jobs fill waves 0-2: wave 3, idle otherwise, runs the whole chunk's v_value path meanwhile (depthwise
             // conv of the fourth kind straight to global: no transform) - four (channel, patch, row) jobs per lane
+            int t3 = threadIdx.x;
+            if constexpr (KST >= 4) asm volatile("" : "+v"(t3));       // (C = 64: row / px / kh rebuilt here, or the base address below is spilled)
+            const int row3 = t3 & 7, px3 = (t3 >> 3) & 3, kh3 = (t3 >> 5) & 1;
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
-                const int elv = 2 * i + kh, ev = e0 + elv;
+                const int elv = 2 * i + (KST >= 4 ? kh3 : kh), ev = e0 + elv;
                 float o8[8];
-                dw_row8(hid + (24 + elv) * FPL + row * FRS + px * 8, wks + (24 + elv) * 9, o8);
+                dw_row8(hid + (24 + elv) * FPL + (KST >= 4 ? row3 * FRS + px3 * 8 : row * FRS + px * 8), wks + (24 + elv) * 9, o8);
                 st_store8<OBF>(o8, rout, ev < E ? opix + (unsigned)(3 * E + ev) * hwo : OOB, 0);
             }
         }
