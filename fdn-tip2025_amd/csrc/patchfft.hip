@@ -963,6 +963,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         }
         FTR(7)
         if (more) stage_store();        // taps and gains of the next chunk (this chunk's were last read before the third barrier)
+        // (measured: an explicit s_waitcnt vmcnt(0) here - what a scratch reload implies - costs 1.8 % at C = 32, 1 % at C = 64: profiles/r05_l_fused64_ab.txt)
         // (the next chunk's row phase rewrites S behind the barrier at the top of the loop, i.e. after every thread has finished these reads)
     }
 }
