@@ -97,6 +97,53 @@ __device__ __forceinline__ void irfft8_row(const float2 (&X)[5], float (&x)[8]) 
 
 __device__ __forceinline__ float rsq(float v) { return __builtin_amdgcn_rsqf(v); }
 
+// One bin (ky of a column kx) of FDSA's recombination, FDN_arch.py:591-629: from the column spectra q, k, v and the gain f = self.fft to
+// u = e^{i(qp - kp)}, v1 = replace_denormals(v f), |qk|, |qk| / |v| and |v| (out1 = |v| u, out2 = |qk| / |v| v1, out3 = |qk| u).
+//   AS_WRITTEN: the four replace_denormals of :593, :597, :603, :604 on every component (16 compare / select instructions per bin).
+//   else      : replace_denormals touches a component only when its magnitude is below 1e-10 - in practice the imaginary parts of the
+//               self-conjugate bins (ky = 0, 4 of the columns kx = 0, 4: exactly 0) and nothing else.  Those four are replaced as written
+//               (SELF_CONJ = ky % 4 == 0); of the other components only the minimum magnitude is tracked in `m`.  The caller takes a wave
+//               vote on m < 1e-10 behind the column and, if some lane needed a replacement, evaluates the column again AS_WRITTEN: the
+//               result is the same bit for bit, the common path issues 45 instructions for the four calls instead of 128.
+// The products that are fused into an fma are spelled out: left to the compiler's contraction the two evaluation paths round differently (its
+// choice depends on the shape of the code around the expression).  The forms below are the ones it had chosen for the as-written code of
+// rounds 1-4 - a b + c d = fma(a, b, c d) everywhere, except the real part of q k, which came out as two rounded products and a subtraction -
+// so the results are those kernels' bit for bit (tools/ab_libs.py, profiles/r05_n_vote.txt).
+__device__ __forceinline__ float fdn_dot2(float a, float b, float c, float d) { return fmaf(a, b, c * d); }      // a b + c d
+__device__ __forceinline__ float fdn_sub_prod(float a, float b, float c, float d) {                             // a b - c d, both products rounded
+#pragma clang fp contract(off)
+    const float p = a * b, r = c * d;
+    return p - r;
+}
+template <bool AS_WRITTEN, bool SELF_CONJ>
+__device__ __forceinline__ void fdsa_bin(float2 q, float2 k, float2 v, float f, float& m, float2& u, float2& v1, float& qka, float& g, float& va) {
+    v1 = make_float2(v.x * f, v.y * f);                                               // :591
+    float2 qk = make_float2(fdn_sub_prod(q.x, k.x, q.y, k.y), fdn_dot2(q.x, k.y, q.y, k.x));      // :595
+    if constexpr (AS_WRITTEN) {
+        v1 = make_float2(rd1(v1.x), rd1(v1.y));                                       // :593
+        qk = make_float2(rd1(qk.x), rd1(qk.y));                                       // :597
+        q = make_float2(rd1(q.x), rd1(q.y));                                          // :603
+        k = make_float2(rd1(k.x), rd1(k.y));                                          // :604
+    } else if constexpr (SELF_CONJ) {
+        v1.y = rd1(v1.y); qk.y = rd1(qk.y); q.y = rd1(q.y); k.y = rd1(k.y);
+        m = fminf(fminf(m, fabsf(v1.x)), fabsf(qk.x));
+        m = fminf(fminf(m, fabsf(q.x)), fabsf(k.x));
+    } else {
+        m = fminf(fminf(m, fabsf(v1.x)), fabsf(v1.y));
+        m = fminf(fminf(m, fabsf(qk.x)), fabsf(qk.y));
+        m = fminf(fminf(m, fabsf(q.x)), fabsf(q.y));
+        m = fminf(fminf(m, fabsf(k.x)), fabsf(k.y));
+    }
+    const float qk2 = fdn_dot2(qk.x, qk.x, qk.y, qk.y), v2 = fdn_dot2(v1.x, v1.x, v1.y, v1.y);
+    qka = qk2 * rsq(qk2);                                                             // |qk|  :599
+    const float iv = rsq(v2);
+    va = v2 * iv;                                                                     // |v|   :601
+    const float nq = rsq(fdn_dot2(q.x, q.x, q.y, q.y)), nk = rsq(fdn_dot2(k.x, k.x, k.y, k.y));
+    const float2 a = make_float2(q.x * nq, q.y * nq), b = make_float2(k.x * nk, k.y * nk);
+    u = make_float2(fdn_dot2(a.x, b.x, a.y, b.y), fdn_dot2(a.y, b.x, -a.x, b.y));            // a conj(b) = e^{i(qp - kp)}  :605-607
+    g = qka * iv;
+}
+
 // buffer resources: per-lane byte offsets are computed once per workgroup (invalid lanes get an offset past
 // num_records, which loads as 0 and drops stores); the channel plane is a scalar offset, so walking planes
 // costs no vector ALU work (these kernels are VALU-issue bound, not HBM bound)

@@ -9,6 +9,10 @@
 // row) computes its own 8 stencil outputs and feeds them straight into the row transform, so the
 // only LDS traffic is the halo tile (one channel at a time, double buffered) and the spectra.
 #include "patch_fft.hpp"
+#include <type_traits>
+#ifndef FDN_RD_VOTE
+#define FDN_RD_VOTE 1      // replace_denormals by wave vote (fdsa_bin, patch_fft.hpp); 0: every compare / select as written (A/B builds)
+#endif
 
 namespace {
 
@@ -182,35 +186,39 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     // ---- columns: thread = (patch, kx): forward, recombine, inverse ---------------------------
     if (tid < NP * 5) {
         const int pj = tid / 5, kx = tid - pj * 5;
-        float2 q[8], k[8], v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            q[i] = S[(0 * NP + pj) * PS + kx * KXS + i];
-            k[i] = S[(1 * NP + pj) * PS + kx * KXS + i];
-            v[i] = S[(2 * NP + pj) * PS + kx * KXS + i];
-        }
-        fft8<false>(q);
-        fft8<false>(k);
-        fft8<false>(v);
         float2 o1[8], o2[8], o3[8];
+        // the column as written (every replace_denormals on every component), or - first - without them and with a running minimum of the
+        // magnitudes they would test (patch_fft.hpp, fdsa_bin); a wave that meets a value below 1e-10 evaluates its columns again as written
+        auto column = [&](auto as_written) __attribute__((always_inline)) {
+            constexpr bool AW = decltype(as_written)::value;
+            float2 q[8], k[8], v[8];
 #pragma unroll
-        for (int ky = 0; ky < 8; ++ky) {
-            const float f = fg[ky];
-            const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));            // :591-593
-            float2 qk = cmul(q[ky], k[ky]);                                               // :595
-            qk = make_float2(rd1(qk.x), rd1(qk.y));                                       // :597
-            const float qk2 = qk.x * qk.x + qk.y * qk.y, v2 = v1.x * v1.x + v1.y * v1.y;
-            const float qka = qk2 * rsq(qk2);                                             // |qk|  :599
-            const float iv = rsq(v2), va = v2 * iv;                                       // |v|   :601
-            const float2 qr = make_float2(rd1(q[ky].x), rd1(q[ky].y));                    // :603
-            const float2 kr = make_float2(rd1(k[ky].x), rd1(k[ky].y));                    // :604
-            const float nq = rsq(qr.x * qr.x + qr.y * qr.y), nk = rsq(kr.x * kr.x + kr.y * kr.y);
-            float2 u = cmulc(make_float2(qr.x * nq, qr.y * nq), make_float2(kr.x * nk, kr.y * nk));   // e^{i(qp-kp)} :605-607
-            const float g = qka * iv;
-            o1[ky] = make_float2(va * u.x, va * u.y);                                     // :609-612
-            o2[ky] = make_float2(g * v1.x, g * v1.y);                                     // qka e^{i v_p} :617-619
-            o3[ky] = make_float2(qka * u.x, qka * u.y);                                   // :627-629
-        }
+            for (int i = 0; i < 8; ++i) {
+                q[i] = S[(0 * NP + pj) * PS + kx * KXS + i];
+                k[i] = S[(1 * NP + pj) * PS + kx * KXS + i];
+                v[i] = S[(2 * NP + pj) * PS + kx * KXS + i];
+            }
+            fft8<false>(q);
+            fft8<false>(k);
+            fft8<false>(v);
+            float m = 1.0f;
+#pragma unroll
+            for (int ky = 0; ky < 8; ++ky) {
+                float2 u, v1;
+                float qka, g, va;
+                if (ky % 4 == 0) fdsa_bin<AW, true>(q[ky], k[ky], v[ky], fg[ky], m, u, v1, qka, g, va);
+                else fdsa_bin<AW, false>(q[ky], k[ky], v[ky], fg[ky], m, u, v1, qka, g, va);
+                o1[ky] = make_float2(va * u.x, va * u.y);                                     // :609-612
+                o2[ky] = make_float2(g * v1.x, g * v1.y);                                     // qka e^{i v_p} :617-619
+                o3[ky] = make_float2(qka * u.x, qka * u.y);                                   // :627-629
+            }
+            return m;
+        };
+#if FDN_RD_VOTE
+        if (__builtin_amdgcn_ballot_w64(column(std::false_type{}) < 1e-10f) != 0) column(std::true_type{});
+#else
+        column(std::true_type{});
+#endif
         fft8<true>(o1);
         fft8<true>(o2);
         fft8<true>(o3);
@@ -271,6 +279,7 @@ template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as 
 #ifndef FDN_MID_CONV2_LATE
 #define FDN_MID_CONV2_LATE 1
 #endif
+
 __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float* __restrict__ x, const float* __restrict__ w0,
                                                            const float* __restrict__ w2, const float* __restrict__ ffta,
                                                            const float* __restrict__ fftp, float* __restrict__ out, int Hd,
@@ -487,9 +496,34 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #pragma unroll
             for (int i = 0; i < 8; ++i) z[i] = S[pj * PS + kx * KXS + i];
             fft8<false>(z);
+#if FDN_RD_VOTE
+            // replace_denormals (:460) touches a value only when |v| < 1e-10 - in practice the imaginary parts of the four self-conjugate bins
+            // (exactly 0 for kx = 0, 4 at ky = 0, 4) and nothing else.  Those two are replaced as written; for the other 14 values the wave takes
+            // the minimum magnitude and runs the compare / select pairs only when some lane needs one (same result bit for bit; 32 -> 13
+            // instructions on the common path)
+            z[0].y = rd1(z[0].y);
+            z[4].y = rd1(z[4].y);
+            {
+                float m = fminf(fabsf(z[0].x), fabsf(z[4].x));
+#pragma unroll
+                for (int ky = 1; ky < 8; ++ky)
+                    if (ky != 4) m = fminf(fminf(m, fabsf(z[ky].x)), fabsf(z[ky].y));
+                if (__builtin_amdgcn_ballot_w64(m < 1e-10f) != 0) {
+#pragma unroll
+                    for (int ky = 0; ky < 8; ++ky) z[ky] = make_float2(rd1(z[ky].x), rd1(z[ky].y));
+                }
+            }
+#pragma unroll
+            for (int ky = 0; ky < 8; ++ky) {                                                      // :461-468
+                // (the fused products spelled out - the form the compiler chose for the as-written code: bit-identical to it, profiles/r05_n_vote.txt)
+                const float2 a = z[ky], b = filt[ky * 5 + kx];
+                z[ky] = make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+            }
+#else
 #pragma unroll
             for (int ky = 0; ky < 8; ++ky)
                 z[ky] = cmul(make_float2(rd1(z[ky].x), rd1(z[ky].y)), filt[ky * 5 + kx]);     // :461-468
+#endif
             fft8<true>(z);
             constexpr float sc = 1.0f / 64.0f;
 #pragma unroll
@@ -849,89 +883,79 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         // ---- columns: thread = (slot, kx): forward, recombine, inverse (as fdsa_core_kernel) ------------------------
         if (tid < NP * 5) {
             const int pj = tid / 5, kx = tid - pj * 5;
-            float2 q[8], k[8], v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                q[i] = S[(0 * NP + pj) * PS + kx * KXS + i];
-                k[i] = S[(1 * NP + pj) * PS + kx * KXS + i];
-                v[i] = S[(2 * NP + pj) * PS + kx * KXS + i];
-            }
             float fg[8];
 #pragma unroll
             for (int ky = 0; ky < 8; ++ky) fg[ky] = fgs[(pj >> 2) * 40 + ky * 5 + kx];
-            fft8<false>(q);
-            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
-            fft8<false>(k);
-            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
-            fft8<false>(v);
-            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
             constexpr float sc = 1.0f / 64.0f;   // norm='backward'
-            if constexpr (KST >= 4) {
-                // C = 64: 144 registers hold the strips, so the recombination keeps (u, |qk|, |qk| / |v|, |v|, v1) per bin - 56 registers where
-                // o1, o2, o3 take 48 on top of q, k, v - and the three outputs are formed, transformed and parked one after the other (the same
-                // operations on the same values: bit-identical)
-                float2 u_[8], v1_[8];
-                float qka_[8], g_[8], va_[8];
+            // (round 5) the recombination runs without the four replace_denormals of :593-604 first - only the self-conjugate bins' imaginary
+            // parts are replaced, the minimum magnitude of everything else is tracked - and a wave that met a value below 1e-10 evaluates its
+            // columns again as written, from the spectra still in LDS (patch_fft.hpp, fdsa_bin: bit-identical; 128 -> 45 instructions per column)
+            // C = 64: 144 registers hold the strips, so the recombination keeps (u, |qk|, |qk| / |v|, |v|, v1) per bin - 56 registers where o1, o2,
+            // o3 take 48 on top of q, k, v - and the three outputs are formed, transformed and parked one after the other.
+            float2 u_[8], v1_[8];
+            float qka_[8], g_[8], va_[8];
+            auto column = [&](auto as_written) __attribute__((always_inline)) {
+                constexpr bool AW = decltype(as_written)::value;
+                float2 q[8], k[8], v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    q[i] = S[(0 * NP + pj) * PS + kx * KXS + i];
+                    k[i] = S[(1 * NP + pj) * PS + kx * KXS + i];
+                    v[i] = S[(2 * NP + pj) * PS + kx * KXS + i];
+                }
+                fft8<false>(q);
+                if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
+                fft8<false>(k);
+                if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
+                fft8<false>(v);
+                if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
+                float m = 1.0f;
 #pragma unroll
                 for (int ky = 0; ky < 8; ++ky) {
-                    const float f = fg[ky];
-                    const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));
-                    float2 qk = cmul(q[ky], k[ky]);
-                    qk = make_float2(rd1(qk.x), rd1(qk.y));
-                    const float qk2 = qk.x * qk.x + qk.y * qk.y, v2 = v1.x * v1.x + v1.y * v1.y;
-                    const float qka = qk2 * rsq(qk2);
-                    const float iv = rsq(v2), va = v2 * iv;
-                    const float2 qr = make_float2(rd1(q[ky].x), rd1(q[ky].y));
-                    const float2 kr = make_float2(rd1(k[ky].x), rd1(k[ky].y));
-                    const float nq = rsq(qr.x * qr.x + qr.y * qr.y), nk = rsq(kr.x * kr.x + kr.y * kr.y);
-                    u_[ky] = cmulc(make_float2(qr.x * nq, qr.y * nq), make_float2(kr.x * nk, kr.y * nk));
-                    v1_[ky] = v1; qka_[ky] = qka; g_[ky] = qka * iv; va_[ky] = va;
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (ky % 4 == 0) fdsa_bin<AW, true>(q[ky], k[ky], v[ky], fg[ky], m, u_[ky], v1_[ky], qka_[ky], g_[ky], va_[ky]);
+                    else fdsa_bin<AW, false>(q[ky], k[ky], v[ky], fg[ky], m, u_[ky], v1_[ky], qka_[ky], g_[ky], va_[ky]);
+                    if (KST >= 4) __builtin_amdgcn_sched_barrier(0);     // C = 64: one bin at a time, or the kernel spills
                 }
+                return m;
+            };
+#if FDN_RD_VOTE
+            // (C = 64 stays as written: the second evaluation path costs 14 spilled registers there, 1.36 -> 1.42 ms)
+            if constexpr (KST >= 4) column(std::true_type{});
+            else if (__builtin_amdgcn_ballot_w64(column(std::false_type{}) < 1e-10f) != 0) column(std::true_type{});
+#else
+            column(std::true_type{});
+#endif
+            if constexpr (KST >= 4) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     float2 o[8];
 #pragma unroll
                     for (int ky = 0; ky < 8; ++ky)
-                        o[ky] = t == 0 ? make_float2(va_[ky] * u_[ky].x, va_[ky] * u_[ky].y)
-                              : t == 1 ? make_float2(g_[ky] * v1_[ky].x, g_[ky] * v1_[ky].y) : make_float2(qka_[ky] * u_[ky].x, qka_[ky] * u_[ky].y);
+                        o[ky] = t == 0 ? make_float2(va_[ky] * u_[ky].x, va_[ky] * u_[ky].y)                 // :609-612
+                              : t == 1 ? make_float2(g_[ky] * v1_[ky].x, g_[ky] * v1_[ky].y)                 // :617-619
+                                       : make_float2(qka_[ky] * u_[ky].x, qka_[ky] * u_[ky].y);              // :627-629
                     fft8<true>(o);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) S[(t * NP + pj) * PS + kx * KXS + i] = make_float2(o[i].x * sc, o[i].y * sc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-            float2 o1[8], o2[8], o3[8];
+                float2 o1[8], o2[8], o3[8];
 #pragma unroll
-            for (int ky = 0; ky < 8; ++ky) {
-                const float f = fg[ky];
-                const float2 v1 = make_float2(rd1(v[ky].x * f), rd1(v[ky].y * f));            // :591-593
-                float2 qk = cmul(q[ky], k[ky]);                                               // :595
-                qk = make_float2(rd1(qk.x), rd1(qk.y));                                       // :597
-                const float qk2 = qk.x * qk.x + qk.y * qk.y, v2 = v1.x * v1.x + v1.y * v1.y;
-                const float qka = qk2 * rsq(qk2);                                             // |qk|  :599
-                const float iv = rsq(v2), va = v2 * iv;                                       // |v|   :601
-                const float2 qr = make_float2(rd1(q[ky].x), rd1(q[ky].y));                    // :603
-                const float2 kr = make_float2(rd1(k[ky].x), rd1(k[ky].y));                    // :604
-                const float nq = rsq(qr.x * qr.x + qr.y * qr.y), nk = rsq(kr.x * kr.x + kr.y * kr.y);
-                float2 u = cmulc(make_float2(qr.x * nq, qr.y * nq), make_float2(kr.x * nk, kr.y * nk));   // :605-607
-                const float g = qka * iv;
-                o1[ky] = make_float2(va * u.x, va * u.y);                                     // :609-612
-                o2[ky] = make_float2(g * v1.x, g * v1.y);                                     // :617-619
-                o3[ky] = make_float2(qka * u.x, qka * u.y);                                   // :627-629
-                if (KST >= 4) __builtin_amdgcn_sched_barrier(0);     // C = 64 (144 registers of strips): one bin at a time, or the kernel spills
-            }
-            fft8<true>(o1);
-            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
-            fft8<true>(o2);
-            if (KST >= 4) __builtin_amdgcn_sched_barrier(0);
-            fft8<true>(o3);
+                for (int ky = 0; ky < 8; ++ky) {
+                    o1[ky] = make_float2(va_[ky] * u_[ky].x, va_[ky] * u_[ky].y);                            // :609-612
+                    o2[ky] = make_float2(g_[ky] * v1_[ky].x, g_[ky] * v1_[ky].y);                            // :617-619
+                    o3[ky] = make_float2(qka_[ky] * u_[ky].x, qka_[ky] * u_[ky].y);                          // :627-629
+                }
+                fft8<true>(o1);
+                fft8<true>(o2);
+                fft8<true>(o3);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                S[(0 * NP + pj) * PS + kx * KXS + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
-                S[(1 * NP + pj) * PS + kx * KXS + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
-                S[(2 * NP + pj) * PS + kx * KXS + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
-            }
+                for (int i = 0; i < 8; ++i) {
+                    S[(0 * NP + pj) * PS + kx * KXS + i] = make_float2(o1[i].x * sc, o1[i].y * sc);
+                    S[(1 * NP + pj) * PS + kx * KXS + i] = make_float2(o2[i].x * sc, o2[i].y * sc);
+                    S[(2 * NP + pj) * PS + kx * KXS + i] = make_float2(o3[i].x * sc, o3[i].y * sc);
+                }
             }
         } else if (!CELLS && wave == 3) {
             // the 160 column jobs fill waves 0-2: wave 3, idle otherwise, runs the whole chunk's v_value path meanwhile (depthwise

@@ -1,4 +1,4 @@
-"""Interleaved A/B timing of several builds of libfdn_hip.so in ONE process: tools/ab_libs.py [--l2] [kernel,...] lib.so [lib.so ...]
+"""Interleaved A/B timing of several builds of libfdn_hip.so in ONE process: tools/ab_libs.py [--edge] [--l2] [kernel,...] lib.so [lib.so ...]
 Sequential runs of two builds differ by up to 15 % on this part (clock / temperature), so the builds take turns: R rounds of
 (lib A x n, lib B x n, ...), median per build.  Kernels: mid, fused, gate, tail, core, out (level-1 shapes, B = 8; --l2: level 2)."""
 import ctypes, os, statistics, sys
@@ -10,6 +10,9 @@ from fdn_hip import ops
 
 args = sys.argv[1:]
 lvl = 1
+edge = False
+if args and args[0] == "--edge":          # zero patches, tiny values and an exact constant in the inputs: the replace_denormals paths are exercised
+    edge, args = True, args[1:]
 if args and args[0] == "--l2":
     lvl, args = 2, args[1:]
 kernels = args[0].split(",") if args and not args[0].endswith(".so") and args[0] != "default" else ["mid", "fused", "gate", "tail", "core", "out"]
@@ -32,6 +35,13 @@ h = r(B, Hd, H, W); w0, w2, fa, fp = r(Hd, 1, 3, 3), r(Hd, 1, 3, 3), r(Hd, 1, 1,
 wg = r(2 * Hd, 1, 3, 3); wo = r(C, Hd) / Hd ** .5
 wh = r(4 * E, C) / C ** .5; dw, fw = r(4 * E, 1, 3, 3), r(E, 1, 1, 8, 5)
 hid = r(B, 4 * E, H, W); wp = r(C, 3 * E) / (3 * E) ** .5; g3, b3 = r(3 * E), r(3 * E)
+if edge:
+    for t in (x, h, hid):
+        t[:, :, :16, :64] = 0.0
+        t[:, 3::7, 16:24, :] *= 1e-12
+        t[:, 1::5, 32:40, 64:128] = 0.5
+        t[:, :, 48:56, :32] = -0.0
+    stats = ops.chan_stats(x)
 out_h, out_c, out_4e = torch.empty_like(h), torch.empty_like(x), torch.empty_like(hid)
 st_out = torch.empty(B, 1, 2, H * W, device=dev)
 
@@ -89,3 +99,5 @@ for k in kernels:
         for (p, _), o in zip(libs[1:], outs[1:]):
             same = torch.equal(outs[0], o)
             print(f"         {paths[0]} vs {p}: bit-identical {same}" + ("" if same else f", max |diff| {(outs[0] - o).abs().max().item():.3e}, nan {int(torch.isnan(o).sum())}"), flush=True)
+            if not same and k in ("core", "fused"):         # which of out1 | out2 | out3 | v_value differ
+                print("           per output: " + " ".join(f"{n}={torch.equal(a_, b_)}" for n, a_, b_ in zip(("out1", "out2", "out3", "vv"), outs[0].chunk(4, 1), o.chunk(4, 1))), flush=True)
