@@ -271,8 +271,11 @@ class Upsample(nn.Module):
     def __init__(self, n_feat):
         super().__init__()
         self.body = nn.Sequential(nn.Identity(), nn.Conv2d(n_feat, n_feat // 2, 3, stride=1, padding=1, bias=False))
+        self._c = _Cache()
 
     def forward(self, x):
+        if ops.UPCONV_GATHER:               # the channel contraction first, at low resolution; the x2 image is never formed
+            return ops.upsample_conv3x3(x, _w(self.body[1].weight), cache=(self._c, "up"))
         return ops.conv2d(ops.resample(x, ops.RS_BILINEAR_X2), _w(self.body[1].weight), pad=1)
 
 

@@ -5,6 +5,7 @@
 //                         :174-175,:192-193,:196), LPNet's 7x7 s2, 3x3 and strided 1x1 convs
 //                         (LPNet_arch.py:49-62,:91)
 //   fdn_conv_transpose4x4s2 : ConvTranspose2d(k=4,s=2,p=1) + LeakyReLU (FDN_arch.py:21-23,:194-195)
+//   fdn_upconv_gather     : the tap sum of Upsample's 3x3 conv over the bilinear x2 image, from the per-tap 1x1 products at low resolution (:726-734)
 //   fdn_resample        : bilinear 1/2 and x2 (align_corners=False), nearest 1/2 and x2,
 //                         PixelUnshuffle (FDN_arch.py:199-206,:230-233,:719,:730,:866)
 // Thread = one output pixel (lanes contiguous along W), OCB output channels in registers; the
@@ -367,6 +368,72 @@ __global__ __launch_bounds__(256) void resample4_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(out + (pl * OH + oy) * OW + 4 * t) = o;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Upsample (FDN_arch.py:726-734): Conv2d(C, C / 2, 3, padding 1) of the bilinear x2 image, WITHOUT the x2 image.  The conv's channel
+// contraction commutes with the (per-channel, linear) upsampling: conv(up(x))[co] = sum over the nine taps of shift_tap(up(z_tap[co])) with
+// z_tap = W_tap x, a 1x1 conv at LOW resolution (fdn_conv1x1, 9 Cout output channels: a quarter of the 3x3 conv's matrix work).  This
+// kernel is the rest: thread = one low-resolution pixel (i, j) = one 2 x 2 output quad, COB output channels.  An output row 2i + p reads,
+// through tap d, the x2 row 2i + p + d - 1 - one of FOUR rows (2i - 1 .. 2i + 2), each a two-tap blend of the low-resolution rows
+// i - 1, i, i + 1 (align_corners = False: 0.75 / 0.25, the source index clamped at the image edge) or nothing at all (the conv's zero
+// padding, outside the x2 image).  V[r][a] are those blends for the rows, U[c][b] for the columns:
+//     out[co][2i + p][2j + q] = sum_{d, e} sum_{a, b} V[p + d][a] U[q + e][b] z[(3d + e) Cout + co][i + a][j + b].
+// ------------------------------------------------------------------------------------------------
+template <int COB>
+__global__ __launch_bounds__(256) void upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout, int h, int w) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (unsigned)(h * w)) return;
+    const int i = (int)(idx / (unsigned)w), j = (int)idx - i * w;
+    const int co0 = blockIdx.y * COB, b = blockIdx.z;
+    const long p_lo = (long)h * w, p_hi = 4 * p_lo;
+    // blends of the four x2 rows / columns around the quad over the low-resolution offsets -1, 0, +1
+    float V[4][3], U[4][3];
+    {
+        const bool t = i == 0, e_ = i == h - 1, l = j == 0, r = j == w - 1;
+        V[0][0] = t ? 0.f : 0.75f; V[0][1] = t ? 0.f : 0.25f; V[0][2] = 0.f;                  // x2 row 2i - 1 (outside the image at i = 0)
+        V[1][0] = t ? 0.f : 0.25f; V[1][1] = t ? 1.f : 0.75f; V[1][2] = 0.f;                  // 2i: rows i - 1 (clamped), i
+        V[2][0] = 0.f; V[2][1] = e_ ? 1.f : 0.75f; V[2][2] = e_ ? 0.f : 0.25f;                // 2i + 1: rows i, i + 1 (clamped)
+        V[3][0] = 0.f; V[3][1] = e_ ? 0.f : 0.25f; V[3][2] = e_ ? 0.f : 0.75f;                // 2i + 2 (outside at i = h - 1)
+        U[0][0] = l ? 0.f : 0.75f; U[0][1] = l ? 0.f : 0.25f; U[0][2] = 0.f;
+        U[1][0] = l ? 0.f : 0.25f; U[1][1] = l ? 1.f : 0.75f; U[1][2] = 0.f;
+        U[2][0] = 0.f; U[2][1] = r ? 1.f : 0.75f; U[2][2] = r ? 0.f : 0.25f;
+        U[3][0] = 0.f; U[3][1] = r ? 0.f : 0.25f; U[3][2] = r ? 0.f : 0.75f;
+    }
+    const int ro[3] = {max(i - 1, 0) * w, i * w, min(i + 1, h - 1) * w};
+    const int cl[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
+    const float* zb = z + (long)b * 9 * Cout * p_lo;
+    float* ob = out + (long)b * Cout * p_hi + (long)(2 * i) * (2 * w) + 2 * j;
+#pragma unroll 1
+    for (int c = 0; c < COB; ++c) {
+        const int co = co0 + c;
+        if (co >= Cout) break;
+        float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const float* zp = zb + (long)((3 * d + e) * Cout + co) * p_lo;
+                // tap d touches the x2 rows d (p = 0) and d + 1 (p = 1): low-resolution offsets {-1, 0}, {-1, 0, 1}, {0, 1} for d = 0, 1, 2
+#pragma unroll
+                for (int a = (d == 2 ? 1 : 0); a < (d == 0 ? 2 : 3); ++a) {
+                    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                    for (int bb = (e == 2 ? 1 : 0); bb < (e == 0 ? 2 : 3); ++bb) {
+                        const float v = zp[ro[a] + cl[bb]];
+                        t0 = fmaf(U[e][bb], v, t0);
+                        t1 = fmaf(U[e + 1][bb], v, t1);
+                    }
+                    o00 = fmaf(V[d][a], t0, o00);
+                    o01 = fmaf(V[d][a], t1, o01);
+                    o10 = fmaf(V[d + 1][a], t0, o10);
+                    o11 = fmaf(V[d + 1][a], t1, o11);
+                }
+            }
+        float* op = ob + (long)co * p_hi;
+        *reinterpret_cast<float2*>(op) = make_float2(o00, o01);
+        *reinterpret_cast<float2*>(op + 2 * w) = make_float2(o10, o11);
+    }
+}
+
 // fourier_fuse.fpre[1]: Conv2d(n, n, 1, padding=1, groups=n): (H+2)x(W+2) map, bias-only border
 __global__ __launch_bounds__(256) void dw1x1_pad1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out, int C, int H,
@@ -645,6 +712,16 @@ extern "C" int fdn_resample(const float* x, float* out, long planes, int H, int 
         hipLaunchKernelGGL(resample_kernel, dim3(cdiv(OW, 256), OH, (unsigned)np), dim3(256), 0, static_cast<hipStream_t>(stream),
                            x + in_pl * H * W, out + p0 * OH * OW, np, H, W, OH, OW, mode, r);
     }
+    return fdn_launch_status();
+}
+
+extern "C" int fdn_upconv_gather(const float* z, float* out, int B, int Cout, int h, int w, fdn_stream_t stream) {
+    FDN_CHECK_ARG(z && out && B > 0 && Cout > 0 && h > 0 && w > 0 && B < 65536);
+    FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+    if ((long)h * w > 0x7FFFFFFFL / 4) return FDN_ERR_UNSUPPORTED;
+    constexpr int COB = 8;
+    hipLaunchKernelGGL(upconv_gather_kernel<COB>, dim3((unsigned)cdiv((long)h * w, 256), (unsigned)cdiv(Cout, COB), (unsigned)B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), z, out, Cout, h, w);
     return fdn_launch_status();
 }
 

@@ -545,6 +545,23 @@ def conv_transpose4x4s2(x, w, bias, act):
     return out
 
 
+UPCONV_GATHER = True        # Upsample as a low-resolution 1x1 conv per tap + fdn_upconv_gather (False: fdn_resample x2 + the 3x3 conv; A/B runs)
+
+
+def upsample_conv3x3(x, w, cache=None):
+    """Conv2d(C, Cout, 3, padding=1, bias=False) of the bilinear x2 image of x (FDN_arch.py:726-734) without that image: the nine per-tap
+    1x1 products at low resolution (one fdn_conv1x1, weight rearranged to [9 Cout, C]: a quarter of the conv's matrix work), then
+    fdn_upconv_gather sums the taps' bilinear samples per output pixel."""
+    B, C, h, w_ = x.shape
+    Cout = w.shape[0]
+    build = lambda: w.detach().permute(2, 3, 0, 1).reshape(9 * Cout, C).contiguous()        # row (3 dy + dx) Cout + co
+    wr = cache[0].get(cache[1] + ":taps", [w], build) if cache is not None else build()
+    z = conv1x1(x, wr, cache=None if cache is None else (cache[0], cache[1] + ":z"))
+    out = torch.empty((B, Cout, 2 * h, 2 * w_), device=x.device, dtype=torch.float32)
+    check(lib().fdn_upconv_gather(_flat(z, "z"), _flat(out, "out"), B, Cout, h, w_, stream()), "fdn_upconv_gather")
+    return out
+
+
 def resample(x, mode, r=1):
     B, C, H, W = x.shape
     if mode in (RS_BILINEAR_HALF, RS_NEAREST_HALF):

@@ -273,6 +273,13 @@ int fdn_fft_cols_inv_polar(const float* mag, const float* pha, int Hin, int Wfin
 int fdn_conv2d(const float* x, const float* w, const float* bias, const float* res, float* out, int B, int Cin, int H,
                int W, int Cout, int KH, int KW, int stride, int pad, int act, int res_before_act, float post_add,
                fdn_stream_t stream);
+/* ABI 14.  Upsample = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) + Conv2d(C, C/2, 3, padding=1, bias=False)
+ * (FDN_arch.py:726-734) without the x2 image: the conv's channel contraction commutes with the upsampling, so the caller first forms the
+ * nine per-tap products z[(3 dy + dx) Cout + co] = sum_ci w[co][ci][dy][dx] x[ci] at LOW resolution (one fdn_conv1x1 with the weight
+ * rearranged to [9 Cout][Cin]) and this entry point sums, for every output pixel, the nine taps' bilinear samples of them (zero outside the
+ * x2 image = the conv's padding; source index clamped at the edge as align_corners=False does).
+ * z [B][9 Cout][h][w] -> out [B][Cout][2h][2w]. */
+int fdn_upconv_gather(const float* z, float* out, int B, int Cout, int h, int w, fdn_stream_t stream);
 /* ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1) + act; weight [Cin][Cout][4][4] (FDN_arch.py:194-195). */
 int fdn_conv_transpose4x4s2(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W,
                             int Cout, int act, fdn_stream_t stream);

@@ -416,6 +416,25 @@ def test_conv1x1_split_bf16_kernel(A, K, N, H, W, pro, epi):
     assert torch.equal(again, got)
 
 
+@pytest.mark.parametrize("C,Cout,h,w,B", [(64, 32, 23, 40, 2), (128, 64, 12, 20, 2), (48, 24, 7, 9, 1), (96, 48, 5, 3, 1), (10, 5, 1, 1, 2), (16, 8, 1, 6, 1),
+                                          (16, 8, 5, 1, 1), (64, 32, 184, 320, 1)])
+def test_upsample_conv_without_the_x2_image(A, C, Cout, h, w, B):
+    """Upsample (FDN_arch.py:726-734: bilinear x2, align_corners=False, then Conv2d 3x3 padding 1 without bias) as nine per-tap 1x1 products at low
+    resolution + fdn_upconv_gather (round 5): against float64 torch and against the route it replaces (fdn_resample x2 + fdn_conv2d), at the bound of
+    that route.  Shapes: the two widths of FDN, FDN_lolv1's, one-pixel and one-row / one-column images (every edge blend at once), the level-2 frame."""
+    from fdn_hip import ops
+    F = torch.nn.functional
+    x, wt = _rnd(B, C, h, w, seed=1), _rnd(Cout, C, 3, 3, seed=2) / (3 * C ** 0.5)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False), wt.double(), padding=1)
+    got = ops.upsample_conv3x3(dev(x), dev(wt), cache=(ops.WeightCache(), "up"))
+    old = ops.conv2d(ops.resample(dev(x), ops.RS_BILINEAR_X2), dev(wt), pad=1)
+    assert got.shape == ref.shape
+    e_new, e_old = rel_rms(got.cpu(), ref), rel_rms(old.cpu(), ref)
+    assert e_new < 2e-6 and e_new < 1.5 * e_old + 5e-8, (e_new, e_old)
+    assert (got.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert rel_rms(ops.upsample_conv3x3(dev(x), dev(wt)).cpu(), ref) < 2e-6        # without a weight cache: the fp32-MFMA GEMMs
+
+
 @pytest.mark.parametrize("K,N,H,W,pro", [(459, 128, 23, 41, "ln3"), (345, 128, 8, 17, "ln3"), (300, 128, 9, 21, "ln3"), (459, 128, 184, 320, "ln3"),
                                         (128, 128, 23, 40, "muladd"), (100, 130, 9, 13, "muladd"), (114, 32, 24, 40, "ln3")])
 def test_gemm_takes_its_own_layernorm_statistics(A, K, N, H, W, pro):
