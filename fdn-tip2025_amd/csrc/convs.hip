@@ -380,7 +380,9 @@ __global__ __launch_bounds__(256) void resample4_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 template <int COB>
 __global__ __launch_bounds__(256) void upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout, int h, int w) {
-    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    // every XCD walks a contiguous run of pixel blocks: a block's source rows i - 1 .. i + 1 are its neighbours' too:
+    // 0.89 -> 0.83 ms at level 1.  (Two quads per thread - 8-byte loads, 16-byte stores, half the load instructions - measured slower: 1.05 ms)
+    const unsigned idx = xcd_contiguous(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
     if (idx >= (unsigned)(h * w)) return;
     const int i = (int)(idx / (unsigned)w), j = (int)idx - i * w;
     const int co0 = blockIdx.y * COB, b = blockIdx.z;

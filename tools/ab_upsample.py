@@ -3,6 +3,9 @@ fdn_upconv_gather, interleaved; per-launch times of the new route's two kernels 
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+import fdn_hip
+if len(sys.argv) > 1:                      # tools/ab_upsample.py [lib.so]: another build of the library
+    fdn_hip._LIB_PATH = os.path.abspath(sys.argv[1])
 import torch
 from fdn_hip import ops
 dev = torch.device("cuda:0")
