@@ -506,6 +506,7 @@ def main():
                     "(since round 5 the default runs it on the bf16 matrix pipe)")
     ap.add_argument("--stats-launches", action="store_true", help="A/B: fdn_chan_stats launches in front of the level-3 LN3 / FCAFFN GEMMs instead of the in-kernel statistics pass")
     ap.add_argument("--resample-upsample", action="store_true", help="A/B: Upsample as fdn_resample x2 + the 3x3 conv instead of the low-resolution 1x1 conv per tap + fdn_upconv_gather")
+    ap.add_argument("--aff-resized", action="store_true", help="A/B: MAR's fourier_fuse on nearest-resized copies (one 84-channel 1x1 conv) instead of one 1x1 conv per source resolution")
     ap.add_argument("--unfused-mlps", action="store_true", help="A/B: MAR's per-bin MLPs as four fdn_conv1x1 launches per block instead of one fdn_spectral_mlp2")
     ap.add_argument("--cpu-720p", action="store_true", help="cpu_baseline also times ONE real 736 x 1280 oracle forward (BASELINE.md 4.3 'single timed run at "
                     "720p': minutes of host time, off by default; the committed line is profiles/r05_cpu_720p.json)")
@@ -577,6 +578,7 @@ def main():
         fdn_hip.ops.SPECTRAL_MLP_FUSED = not a.unfused_mlps
         fdn_hip.ops.GEMM_OWN_STATS = not a.stats_launches
         fdn_hip.ops.UPCONV_GATHER = not a.resample_upsample
+        fdn_hip.ops.AFF_MULTIRES = not a.aff_resized
         net, lp = build_models(dev, a.variant)
         x = make_input(a.batch, a.height, a.width, dev, seed=1000 + rank)
         mk = lambda r: make_input(a.batch, a.height, a.width, dev, seed=1000 + r)
@@ -670,7 +672,7 @@ def main():
         total_ms = sum(v[2] for v in agg.values())
         # figures taken from the committed PMC passes describe the DEFAULT routing of the code they were recorded on: with an A/B route
         # switched on (--fdsa-full, --narrow-pipe) the kernels differ, so nothing is borrowed from them
-        default_routing = not (a.fdsa_full or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample)
+        default_routing = not (a.fdsa_full or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
         prof = matching_profile([B, a.height, a.width], a.dtype) if (a.config == "fdn" and a.variant == "lolblur" and default_routing) else None
         traffic = {k: v["hbm_bytes_per_launch"] for k, v in prof["groups"].items()} if prof else {}
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][2])
@@ -698,7 +700,7 @@ def main():
     # graph, untimed warm-up, K steps between synchronisations), so that every run of the headline command records them too (VERDICT r4, row g)
     other = None
     if (rank == 0 and world == 1 and not a.dry_run and not a.no_other_configs and a.config == "fdn" and a.variant == "lolblur" and a.graph
-            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample)):
+            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
         from fdn_hip.pipeline import GraphedStep
 
         def side(fn, xin, steps=3):
@@ -769,7 +771,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                        "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample),
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
                        "host_issue_ms_per_step": host_issue_ms, "cpu_affinity_rank0": affinity},
             # B_alg = 7,256 elements per padded pixel x sizeof(elem) - 4 bytes in fp32, 2 in the bf16-storage configuration
             "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * (ips / world) / (PEAK_HBM_GBS * 1e9),

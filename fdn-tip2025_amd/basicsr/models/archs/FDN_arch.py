@@ -408,10 +408,29 @@ class fourier_fuse(nn.Module):
         self.process1 = nn.Sequential(nn.Conv2d(out_nc, out_nc, 1, 1, 0), nn.LeakyReLU(0.1), nn.Conv2d(out_nc, out_nc, 1, 1, 0))
         self.process2 = nn.Sequential(nn.Conv2d(out_nc, out_nc, 1, 1, 0), nn.LeakyReLU(0.1), nn.Conv2d(out_nc, out_nc, 1, 1, 0))
         self.fourier_out = nn.Conv2d(out_nc, out_nc, 3, 1, 1)
+        self._c = _Cache()
 
     def forward(self, x1, x2, x4):
-        _, _, H, W = x1.shape
-        y = ops.conv1x1([x1, x2, x4], _w(self.fpre[0].weight), _w(self.fpre[0].bias))
+        return self._rest(ops.conv1x1([x1, x2, x4], _w(self.fpre[0].weight), _w(self.fpre[0].bias)))
+
+    def forward_multires(self, same, up1, up2):
+        """forward(cat(same), nearest_x2(up1), nearest_x4(up2)) without the resized tensors (round 5): fpre[0] is a 1x1 conv and nearest
+        replication commutes with it, so every source is contracted at ITS OWN resolution and the (narrow) partial sums are replicated:
+        W [same | up1 | up2] = W_s same + x2(W_1 up1 + x2(W_2 up2)).  MAR_archa.forward's z21 / z41 / z42 (FDN_arch.py:231-236: 72 + 48 planes
+        at the finer levels) are never formed; the sums differ from the reference's single 84-term dot product in association only."""
+        wfull, bias = _w(self.fpre[0].weight), _w(self.fpre[0].bias)
+        n = wfull.shape[0]
+        ks = sum(t.shape[1] for t in same)
+        k1 = 0 if up1 is None else up1.shape[1]
+        w2 = wfull.reshape(n, -1)
+        parts = self._c.get("split", [self.fpre[0].weight], lambda: (w2[:, :ks].contiguous(), w2[:, ks:ks + k1].contiguous(), w2[:, ks + k1:].contiguous()))
+        acc = ops.conv1x1(up2, parts[2])                                               # two levels down
+        if up1 is not None:
+            acc = ops.conv1x1(up1, parts[1], res=ops.resample(acc, ops.RS_NEAREST_X2))   # one level down
+        return self._rest(ops.conv1x1(same, parts[0], bias, res=ops.resample(acc, ops.RS_NEAREST_X2)))
+
+    def _rest(self, y):
+        H, W = y.shape[-2:]
         y = ops.dw1x1_pad1(y, _w(self.fpre[1].weight), _w(self.fpre[1].bias))          # (H+2) x (W+2), :126
         zz = _spectral_mlps(y, self.process1, self.process2, H, W)                      # leading-slice crop, :147
         xo = ops.irfft_rows(zz, H, W, 2.0 / (H * W))
@@ -459,11 +478,16 @@ class MAR_archa(nn.Module):
         res2 = self.Encoder[1](self.FAM2(self.f3_down(res1), z2))
         z = self.Encoder[2](self.FAM1(self.f2_down(res2), z4))
         z12 = ops.resample(res1, ops.RS_NEAREST_HALF)
-        z21 = ops.resample(res2, ops.RS_NEAREST_X2)
-        z42 = ops.resample(z, ops.RS_NEAREST_X2)
-        z41 = ops.resample(z42, ops.RS_NEAREST_X2)
-        res2 = self.AFFs[1](z12, res2, z42)
-        res1 = self.AFFs[0](res1, z21, z41)
+        if ops.AFF_MULTIRES:                 # the 1x1 conv of each fourier_fuse applied per source resolution: no z21 / z42 / z41
+            res2n = self.AFFs[1].forward_multires([z12, res2], None, z)
+            res1 = self.AFFs[0].forward_multires([res1], res2, z)
+            res2 = res2n
+        else:
+            z21 = ops.resample(res2, ops.RS_NEAREST_X2)
+            z42 = ops.resample(z, ops.RS_NEAREST_X2)
+            z41 = ops.resample(z42, ops.RS_NEAREST_X2)
+            res2 = self.AFFs[1](z12, res2, z42)
+            res1 = self.AFFs[0](res1, z21, z41)
         z = self.Decoder[0](z)
         o4 = self.ConvsOut[0](z, res=x_4, res_before_act=True, act=ACT_SIGMOID, post_add=1e-8)
         z = self.f2_up(z)

@@ -545,6 +545,7 @@ def conv_transpose4x4s2(x, w, bias, act):
     return out
 
 
+AFF_MULTIRES = True         # MAR's fourier_fuse 1x1 convs per source resolution (False: nearest-resized copies + one 84-channel conv; A/B runs)
 UPCONV_GATHER = True        # Upsample as a low-resolution 1x1 conv per tap + fdn_upconv_gather (False: fdn_resample x2 + the 3x3 conv; A/B runs)
 
 

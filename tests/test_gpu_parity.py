@@ -416,6 +416,30 @@ def test_conv1x1_split_bf16_kernel(A, K, N, H, W, pro, epi):
     assert torch.equal(again, got)
 
 
+@pytest.mark.parametrize("H,W", [(32, 48), (96, 160)])
+def test_fourier_fuse_per_source_resolution(A, H, W):
+    """MAR's fourier_fuse (FDN_arch.py:120-147) fed from the sources at their own resolutions (round 5: the 1x1 conv fpre[0] commutes with the nearest
+    replication of F.interpolate, :231-236) against the same module on the resized copies, both AFFs' channel layouts."""
+    from fdn_hip import ops
+    torch.manual_seed(5)
+    c = 12
+    for aff, same_c, up1_c in ((A.fourier_fuse(7 * c, c), [c], 2 * c), (A.fourier_fuse(7 * c, 2 * c), [c, 2 * c], 0)):
+        aff = aff.to("cuda:0").eval()
+        same = [dev(_rnd(2, k, H, W, seed=10 + i)) for i, k in enumerate(same_c)]
+        up1 = dev(_rnd(2, up1_c, H // 2, W // 2, seed=20)) if up1_c else None
+        lvl = 4 if up1_c else 2
+        up2 = dev(_rnd(2, 4 * c, H // lvl, W // lvl, seed=21))
+        with torch.no_grad():
+            got = aff.forward_multires(same, up1, up2)
+            big2 = ops.resample(up2, ops.RS_NEAREST_X2)
+            if up1_c:
+                ref = aff(same[0], ops.resample(up1, ops.RS_NEAREST_X2), ops.resample(big2, ops.RS_NEAREST_X2))
+            else:
+                ref = aff(same[0], same[1], big2)
+        assert got.shape == ref.shape
+        assert rel_rms(got.cpu(), ref.cpu().double()) < 2e-6
+
+
 @pytest.mark.parametrize("C,Cout,h,w,B", [(64, 32, 23, 40, 2), (128, 64, 12, 20, 2), (48, 24, 7, 9, 1), (96, 48, 5, 3, 1), (10, 5, 1, 1, 2), (16, 8, 1, 6, 1),
                                           (16, 8, 5, 1, 1), (64, 32, 184, 320, 1)])
 def test_upsample_conv_without_the_x2_image(A, C, Cout, h, w, B):

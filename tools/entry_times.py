@@ -5,8 +5,15 @@ sys.path.insert(0, ROOT)
 import torch
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-flt = [a for a in sys.argv[2:] if not a.endswith(".so")]
+flt = [a for a in sys.argv[2:] if not a.endswith(".so") and "=" not in a]
 for a in sys.argv[2:]:
+    if "=" in a:                              # ops switch for an A/B run, e.g. AFF_MULTIRES=0
+        sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
+        from fdn_hip import ops as _ops
+        k_, v_ = a.split("=")
+        assert hasattr(_ops, k_), k_
+        setattr(_ops, k_, bool(int(v_)))
+        print("ops." + k_, "=", bool(int(v_)))
     if a.endswith(".so"):                     # another build of the same ABI (A/B)
         sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
         import fdn_hip
