@@ -238,7 +238,7 @@ class Fuse(nn.Module):
 
     def forward(self, enc, dnc, x_high=None, x_high_p=None, x_img=None):
         n = self.n_feat
-        x = ops.conv1x1([enc, dnc], _w(self.conv.weight), _w(self.conv.bias), want_stats=True)      # (norm2 of att_channel reads them: no fdn_chan_stats pass)
+        x = ops.conv1x1([enc, dnc], _w(self.conv.weight), _w(self.conv.bias), want_stats=True, cache=(self._c, "c1"))   # (norm2 of att_channel reads the statistics: no fdn_chan_stats pass)
         x = self.att_channel((x, x_high, x_high_p, x_img))[0]
         wf = self._c.get("w", [self.conv2.weight], lambda: self.conv2.weight.detach()[:n] + self.conv2.weight.detach()[n:])
         bf = self._c.get("b", [self.conv2.bias], lambda: self.conv2.bias.detach()[:n] + self.conv2.bias.detach()[n:])

@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
     // ---- staging roles: thread = (pixel xp, k-step hh) handles the 16 k of that step; weights: six 16-byte units ----
     const int xp = tid & (TP - 1), hh = wave >> 1;
     const unsigned pix = min(p0 + (unsigned)xp, P - 1);
-    const rsrc_t rx = mk_rsrc(d.x[0] + (long)b * d.xbs[0], (unsigned)K * P4);
+    // (round 5) two concatenated inputs (Fuse.conv over [enc | dnc], FDN_arch.py:685): a 32-deep chunk lies in one of them (the host checks
+    // kseg[0] % 32 == 0), so the descriptor and the plane offset are chosen per chunk, uniformly
+    const int K0 = d.kseg[1] > 0 ? d.kseg[0] : K;
+    const rsrc_t rx = mk_rsrc(d.x[0] + (long)b * d.xbs[0], (unsigned)K0 * P4);
+    const rsrc_t rx1 = d.kseg[1] > 0 ? mk_rsrc(d.x[1] + (long)b * d.xbs[1], (unsigned)(K - K0) * P4) : rx;
     const rsrc_t rv = mk_rsrc((TRI || LNM) ? d.xb + (long)b * d.xbbs : d.x[0], TRI ? (unsigned)E * P4 : LNM ? (unsigned)K * P4 : 0u);
     const fdn_u32x4* wsrc = reinterpret_cast<const fdn_u32x4*>(d.wpk) + (long)nt * nch * BLK;
     float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};                  // (x - mean) * rstd = x * sa + sb
@@ -182,9 +186,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
             }
         } else {
             const int k0 = c * KC + 16 * hh;
+            const bool second = PRO == FDN_PRO_NONE && k0 >= K0;              // wave-uniform
+            const rsrc_t rxc = second ? rx1 : rx;
+            const int kb = second ? k0 - K0 : k0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                xv[i] = bload(rx, pix * 4u, (unsigned)(k0 + i) * P4);         // k >= K reads 0
+                xv[i] = bload(rxc, pix * 4u, (unsigned)(kb + i) * P4);        // k >= K reads 0
                 if constexpr (LNM) {
                     vv[i] = bload(rv, pix * 4u, (unsigned)(k0 + i) * P4);
                     ga[i] = k0 + i < K ? d.gamma[k0 + i] : 0.f;
@@ -757,10 +764,12 @@ int fdn_gemm_split(const fdn_conv1x1_desc& d, hipStream_t s) {
     if (fdn_matrix_pipe_f32()) return FDN_ERR_UNSUPPORTED;
     // lanes past the pixel count are masked with a byte offset of 2^31: it must stay outside every descriptor of this kernel
     if ((unsigned long long)(d.N > d.K ? d.N : d.K) * 4ull * (unsigned long long)d.P > 0x7FFFFFFFull) return FDN_ERR_UNSUPPORTED;
-    if (!d.wpk || d.kseg[1] > 0 || d.kseg[2] > 0 || d.act != FDN_ACT_NONE || d.x_bf16 || d.out_bf16) return FDN_ERR_UNSUPPORTED;
+    if (!d.wpk || d.kseg[2] > 0 || d.act != FDN_ACT_NONE || d.x_bf16 || d.out_bf16) return FDN_ERR_UNSUPPORTED;
+    const bool two = d.kseg[1] > 0;                       // two inputs: the K-streaming kernel only, plain prologue, whole chunks per input
+    if (two && (d.pro != FDN_PRO_NONE || d.kseg[0] % KC != 0 || d.K < 96 || d.N < 96)) return FDN_ERR_UNSUPPORTED;
     if ((long)d.B * cdiv(d.P, TP) * cdiv(d.N, TN) > 0x7FFFFFFFL) return FDN_ERR_UNSUPPORTED;
     // short K, wide N, no epilogue: the activation strip stays in registers and the weights stream
-    const bool strip = d.N <= STRIP_MAX_N && d.epi == FDN_EPI_NONE && !d.stats_out && (d.pro == FDN_PRO_NONE || d.pro == FDN_PRO_LN);
+    const bool strip = !two && d.N <= STRIP_MAX_N && d.epi == FDN_EPI_NONE && !d.stats_out && (d.pro == FDN_PRO_NONE || d.pro == FDN_PRO_LN);
     // (round 3) the project_in convs of levels 1-2 as well (32 -> 86, 64 -> 172; FDN_lolv1 24 -> 64, 48 -> 129): on the fp32 MFMA they kept
     // the vector ALU's datapath 60-90 % busy (64 -> 172: 0.49 -> 0.41 ms, 32 -> 86: 0.82 -> 0.75 ms here)
     if (strip && d.K > 16 && d.K <= 64 && 2 * d.N >= 5 * d.K) {

@@ -167,7 +167,7 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
         d.pro = PRO_LN_MULADD
         d.stats, d.gamma, d.beta = _flat(ln_muladd[0], "stats"), _flat(ln_muladd[1], "gamma"), _flat(ln_muladd[2], "beta")
         d.xb, d.xbbs = _planes(ln_muladd[3], "x1")
-    if (cache is not None and ((K >= 96 and N >= 96) or (16 < K <= 64 and 2 * N >= 5 * K and res is None and muladd is None and not want_stats)) and len(xs) == 1 and act == ACT_NONE and xs[0].dtype == torch.float32
+    if (cache is not None and ((K >= 96 and N >= 96) or (16 < K <= 64 and 2 * N >= 5 * K and res is None and muladd is None and not want_stats)) and (len(xs) == 1 or (len(xs) == 2 and K >= 96 and N >= 96 and xs[0].shape[1] % 32 == 0 and d.pro == PRO_NONE)) and act == ACT_NONE and xs[0].dtype == torch.float32
             and out.dtype == torch.float32):
         srcs = [w0, bias0] + (list(ln[1:3]) if ln is not None else [])
         d.wpk = ctypes.c_void_p(cache[0].get(cache[1] + ":pk", srcs, lambda w=w: conv1x1_pack(

@@ -416,6 +416,27 @@ def test_conv1x1_split_bf16_kernel(A, K, N, H, W, pro, epi):
     assert torch.equal(again, got)
 
 
+@pytest.mark.parametrize("K0,K1,N,H,W", [(64, 64, 128, 23, 41), (96, 32, 96, 9, 13), (64, 64, 128, 368, 640), (32, 96, 130, 8, 17)])
+def test_conv1x1_two_inputs_on_the_split_bf16_kernel(A, K0, K1, N, H, W):
+    """Fuse.conv (FDN_arch.py:685: a 1x1 conv over cat([enc, dnc])) at level 2 on the K-streaming split-bf16 kernel (round 5: the descriptor is chosen
+    per 32-deep chunk): against float64, with bias, the statistics epilogue, and against the fp32-MFMA route."""
+    from fdn_hip import ops
+    B = 2 if H < 100 else 1
+    x0, x1 = _rnd(B, K0, H, W, seed=1), _rnd(B, K1, H, W, seed=2) * 0.7 + 0.1
+    w, bias = _rnd(N, K0 + K1, seed=3) / (K0 + K1) ** 0.5, _rnd(N, seed=4)
+    ref = torch.nn.functional.conv2d(torch.cat([x0, x1], 1).double(), w.double().view(N, -1, 1, 1), bias.double())
+    wc = ops.WeightCache()
+    want = N <= 128
+    got = ops.conv1x1([dev(x0), dev(x1)], dev(w), dev(bias), want_stats=want, cache=(wc, "t"))
+    assert any(k.endswith(":pk") for k in wc._store), "the packed-weight path was not taken"
+    plain = ops.conv1x1([dev(x0), dev(x1)], dev(w), dev(bias), want_stats=want)
+    e_split, e_f32 = rel_rms(got.cpu(), ref), rel_rms(plain.cpu(), ref)
+    assert e_split < 2e-6 and e_split < 1.5 * e_f32 + 2e-8, (e_split, e_f32)
+    if want:
+        st = got._fdn_stats.cpu().view(B, 2, H, W)
+        assert rel_rms(st[:, 0], ref.mean(1)) < 1e-5 and rel_rms(st[:, 1], 1 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5)) < 1e-5
+
+
 @pytest.mark.parametrize("H,W", [(32, 48), (96, 160)])
 def test_fourier_fuse_per_source_resolution(A, H, W):
     """MAR's fourier_fuse (FDN_arch.py:120-147) fed from the sources at their own resolutions (round 5: the 1x1 conv fpre[0] commutes with the nearest
