@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void resample4_kernel(const float* __restrict_
 //     out[co][2i + p][2j + q] = sum_{d, e} sum_{a, b} V[p + d][a] U[q + e][b] z[(3d + e) Cout + co][i + a][j + b].
 // ------------------------------------------------------------------------------------------------
 template <int COB>
-__global__ __launch_bounds__(256) void upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout, int h, int w) {
+__global__ __launch_bounds__(256, 2) void upconv_gather_kernel(const float* __restrict__ z, float* __restrict__ out, int Cout, int h, int w) {
     // every XCD walks a contiguous run of pixel blocks: a block's source rows i - 1 .. i + 1 are its neighbours' too:
     // 0.89 -> 0.83 ms at level 1.  (Two quads per thread - 8-byte loads, 16-byte stores, half the load instructions - measured slower: 1.05 ms)
     const unsigned idx = xcd_contiguous(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float* __restr
     const int cl[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
     const float* zb = z + (long)b * 9 * Cout * p_lo;
     float* ob = out + (long)b * Cout * p_hi + (long)(2 * i) * (2 * w) + 2 * j;
-#pragma unroll 1
+    // (two channels in flight per thread - 98 loads - at two waves per SIMD: 0.83 -> 0.78 ms; more waves with fewer registers lose: 1.02 ms at four)
+#pragma unroll 2
     for (int c = 0; c < COB; ++c) {
         const int co = co0 + c;
         if (co >= Cout) break;
@@ -721,7 +722,7 @@ extern "C" int fdn_upconv_gather(const float* z, float* out, int B, int Cout, in
     FDN_CHECK_ARG(z && out && B > 0 && Cout > 0 && h > 0 && w > 0 && B < 65536);
     FDN_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 7) == 0);
     if ((long)h * w > 0x7FFFFFFFL / 4) return FDN_ERR_UNSUPPORTED;
-    constexpr int COB = 8;
+    constexpr int COB = 8;                 // (2 / 4 / 16 channels per thread: 0.88 / 0.95 / 0.80 ms against 0.82)
     hipLaunchKernelGGL(upconv_gather_kernel<COB>, dim3((unsigned)cdiv((long)h * w, 256), (unsigned)cdiv(Cout, COB), (unsigned)B), dim3(256), 0,
                        static_cast<hipStream_t>(stream), z, out, Cout, h, w);
     return fdn_launch_status();
