@@ -126,8 +126,6 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     const int ngrp = (E + EPB - 1) / EPB;
     const unsigned item = xcd_contiguous(blockIdx.x, gridDim.x);           // (b, channel group, tile), tile fastest
     const int tile = item % ntiles, e_first = ((item / ntiles) % ngrp) * EPB, b = item / (ntiles * ngrp);
-    for (int e = e_first; e < e_first + EPB && e < E; ++e) {
-    if (e != e_first) __syncthreads();                                     // the previous channel's inverse rows have read the spectra
     const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const unsigned hw4 = (unsigned)H * W * 4u;                  // bytes per plane; 4E planes per image < 4 GB (checked by the host)
     const long base = (long)b * 4 * E * H * W;
@@ -138,15 +136,6 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     const int gy = ty0 + py * 8 + rr, gx = tx0 + px * 8;
     const bool inside = gy < H && gx < W;          // patches are entirely inside or outside (H, W % 8 == 0)
     const unsigned ooff = inside ? (unsigned)(gy * W + gx) * 4u : OOB;
-
-    // the column-phase gains of this channel (thread = (patch, kx)) are requested first: their latency hides behind
-    // the whole row phase instead of stalling the column phase
-    float fg[8];
-    {
-        const int kxc = tid < NP * 5 ? tid % 5 : 0;
-#pragma unroll
-        for (int ky = 0; ky < 8; ++ky) fg[ky] = fftw[(e * 8 + ky) * 5 + kxc];
-    }
     unsigned goff[HPT];
     int slot[HPT];
     float pre[HPT];
@@ -162,8 +151,18 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
     };
     if (V4) hv = halo_v4_setup<1, HS, TH + 2>(H, W, ty0, tx0);
     else halo_offsets(H, W, ty0, tx0, goff, slot);
-    fetch(e);
-    stash(halo[0]);
+    fetch(e_first);
+    for (int e = e_first; e < e_first + EPB && e < E; ++e) {
+    if (e != e_first) __syncthreads();                                     // the previous channel's inverse rows have read the spectra
+    // the column-phase gains of this channel (thread = (patch, kx)) are requested first: their latency hides behind
+    // the whole row phase instead of stalling the column phase
+    float fg[8];
+    {
+        const int kxc = tid < NP * 5 ? tid % 5 : 0;
+#pragma unroll
+        for (int ky = 0; ky < 8; ++ky) fg[ky] = fftw[(e * 8 + ky) * 5 + kxc];
+    }
+    stash(halo[0]);                       // this channel's q plane: requested before the loop / behind the previous channel's column phase
     __syncthreads();
 
 #pragma unroll
@@ -182,6 +181,10 @@ __global__ __launch_bounds__(256, 3) void fdsa_core_kernel(const float* __restri
         __syncthreads();
     }
     // (halo[1] now holds the v_value plane: its depthwise conv goes straight out, from the wave the column phase leaves idle)
+    // (round 5) the NEXT channel's q plane travels during this channel's column and inverse phases - it used to be requested at the top of the
+    // channel and waited for on the spot, one exposed memory round trip per channel: level 3 0.501 -> 0.487 ms, bit-identical.  (Two planes in
+    // flight throughout - a second register set, 168 registers - measured the same: 0.486 ms)
+    if (e + 1 < e_first + EPB && e + 1 < E) fetch(e + 1);
 
     // ---- columns: thread = (patch, kx): forward, recombine, inverse ---------------------------
     if (tid < NP * 5) {
