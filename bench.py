@@ -112,6 +112,12 @@ def _describe_fdsa_fused(c):
     return f"fdn_fdsa_fused[C={C},E={E},{H}x{W}{',obf16' if ob == 2.0 else ''}]", 2.0 * B * H * W * C * 4 * E, B * H * W * (4.0 * C + ob * 4 * E)
 
 
+def _describe_fdsa_fused_tail(c):
+    # the whole sub-block: x in, res in, out + statistics out (the tile-local scratch is not algorithmic traffic); both 1x1 convs' flops
+    B, C, E, H, W = c.i("B", "C", "E", "H", "W")
+    return f"fdn_fdsa_fused_tail[C={C},E={E},{H}x{W}]", 2.0 * B * H * W * (C * 4 * E + 3 * E * C), 4.0 * B * H * W * (3 * C + 4)
+
+
 def _describe_fdsa_full(c):
     B, C, E, H, W = c.i("B", "C", "E", "H", "W")
     return f"fdn_fdsa_full[C={C},E={E},{H}x{W}]", 2.0 * B * H * W * (C * 4 * E + 3 * E * C), 4.0 * B * H * W * (3 * C + 2)
@@ -207,7 +213,7 @@ def _describe_img_mod_maps(c):
 # entry point -> parser of its call.  tests/test_host_cpu.py feeds every parser a call built from the header's own prototype and checks that
 # the key carries the values under their NAMES; entry points without a parser are grouped under their bare name with no roofline figure.
 DESCRIBERS = {
-    "fdn_conv1x1": _describe_conv1x1, "fdn_fdsa_fused": _describe_fdsa_fused, "fdn_fdsa_full": _describe_fdsa_full,
+    "fdn_conv1x1": _describe_conv1x1, "fdn_fdsa_fused": _describe_fdsa_fused, "fdn_fdsa_fused_tail": _describe_fdsa_fused_tail, "fdn_fdsa_full": _describe_fdsa_full,
     "fdn_fdsa_core": _describe_fdsa_core, "fdn_fdsa_out": _describe_fdsa_out, "fdn_fdffn_mid": _describe_fdffn_mid,
     "fdn_dwconv_gate": _describe_dwconv_gate, "fdn_ffn_tail": _describe_ffn_tail, "fdn_rfft_rows": _describe_rfft_rows,
     "fdn_irfft_rows": _describe_irfft_rows, "fdn_fft_cols_fcaffn": _describe_fft_cols_fcaffn, "fdn_rfft_rows_ln": _describe_rfft_rows_ln,
@@ -512,6 +518,8 @@ def main():
                     "720p': minutes of host time, off by default; the committed line is profiles/r05_cpu_720p.json)")
     ap.add_argument("--fdsa-full", action="store_true", help="A/B: route the level-1 FDSA sub-blocks through fdn_fdsa_full (one launch) instead of "
                     "fdn_fdsa_fused + fdn_fdsa_out (DESIGN.md section 4: built, correct, not the default)")
+    ap.add_argument("--fdsa-pair", action="store_true", help="A/B: the FDSA sub-blocks of levels 1-2 as fdn_fdsa_fused + fdn_fdsa_out (two launches, the 4E-plane hand-off "
+                    "through HBM: the round-5 route) instead of fdn_fdsa_fused_tail")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short side measurements of BASELINE.json configs[2] (1080p B = 4 bf16 storage) "
                     "and configs[4] (LPNet alone) that the default headline run appends as `other_configs`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -573,6 +581,7 @@ def main():
         import fdn_hip
         fdn_hip.set_storage_dtype(a.dtype)
         fdn_hip.ops.FDSA_FULL = bool(a.fdsa_full)
+        fdn_hip.ops.FDSA_TAIL = not a.fdsa_pair
         if a.narrow_pipe:
             fdn_hip.set_matrix_pipe("bf16-narrow")
         fdn_hip.ops.SPECTRAL_MLP_FUSED = not a.unfused_mlps
@@ -672,7 +681,7 @@ def main():
         total_ms = sum(v[2] for v in agg.values())
         # figures taken from the committed PMC passes describe the DEFAULT routing of the code they were recorded on: with an A/B route
         # switched on (--fdsa-full, --narrow-pipe) the kernels differ, so nothing is borrowed from them
-        default_routing = not (a.fdsa_full or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
+        default_routing = not (a.fdsa_full or a.fdsa_pair or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
         prof = matching_profile([B, a.height, a.width], a.dtype) if (a.config == "fdn" and a.variant == "lolblur" and default_routing) else None
         traffic = {k: v["hbm_bytes_per_launch"] for k, v in prof["groups"].items()} if prof else {}
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][2])
@@ -700,7 +709,7 @@ def main():
     # graph, untimed warm-up, K steps between synchronisations), so that every run of the headline command records them too (VERDICT r4, row g)
     other = None
     if (rank == 0 and world == 1 and not a.dry_run and not a.no_other_configs and a.config == "fdn" and a.variant == "lolblur" and a.graph
-            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
+            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.fdsa_pair or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
         from fdn_hip.pipeline import GraphedStep
 
         def side(fn, xin, steps=3):
@@ -771,7 +780,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                        "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "fdsa_pair": bool(a.fdsa_pair), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
                        "host_issue_ms_per_step": host_issue_ms, "cpu_affinity_rank0": affinity},
             # B_alg = 7,256 elements per padded pixel x sizeof(elem) - 4 bytes in fp32, 2 in the bf16-storage configuration
             "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * (ips / world) / (PEAK_HBM_GBS * 1e9),

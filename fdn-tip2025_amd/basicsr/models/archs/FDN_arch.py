@@ -100,6 +100,15 @@ class FDSA(nn.Module):
             srcs = [self.to_hidden.weight] + ([ln[1], ln[2]] if ln is not None else [])
             wpk = self._c.get("pk" if ln is not None else "pk0", srcs, lambda: ops.fdsa_pack(
                 _w(self.to_hidden.weight), *((ln[1], ln[2]) if ln is not None else (None, None))))
+            if ops.FDSA_TAIL and fdn_hip.storage_dtype() == "f32" and (res is None or res.is_contiguous()):
+                # (round 6) one launch: the workgroup that produced a tile's (out1|out2|out3|v_value) planes runs the tail on them itself
+                img = self._c.get("tl", [self.project_out.weight] + [n.body.weight for n in norms] + [n.body.bias for n in norms],
+                                  lambda: ops.fdsa_tail_pack(_w(self.project_out.weight), gam, bet, x.shape[1]))
+                if img is not None:
+                    y = ops.fdsa_fused_tail(x, ln[0] if ln is not None else None, wpk, _w(self.to_hidden_dw.weight), _w(self.fft), img,
+                                            res=res, want_stats=res is not None)
+                    if y is not None:
+                        return y
             o = ops.fdsa_fused(x, ln[0] if ln is not None else None, wpk, _w(self.to_hidden_dw.weight), _w(self.fft),
                                out_dtype=ops.block_storage(x.shape[1], x.shape[2] * x.shape[3]))
         else:

@@ -2,7 +2,7 @@
 #include "common.hpp"
 
 #include <atomic>
-extern "C" int fdn_abi_version(void) { return 14; }
+extern "C" int fdn_abi_version(void) { return 15; }
 
 // Diagnostic switch: 1 = every matrix product of the path on the fp32 MFMA (the round-2 kernels) instead of the split-bf16 forms on
 // v_mfma_f32_32x32x16_bf16, so that the cross-stream finding can be bisected.  Process-wide, default 0.

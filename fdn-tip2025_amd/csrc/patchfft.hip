@@ -9,6 +9,7 @@
 // row) computes its own 8 stencil outputs and feeds them straight into the row transform, so the
 // only LDS traffic is the halo tile (one channel at a time, double buffered) and the spectra.
 #include "patch_fft.hpp"
+#include "fdsa_tail.hpp"
 #include <type_traits>
 #ifndef FDN_RD_VOTE
 #define FDN_RD_VOTE 1      // replace_denormals by wave vote (fdsa_bin, patch_fft.hpp); 0: every compare / select as written (A/B builds)
@@ -593,6 +594,12 @@ struct FusedArgs {
     const float* fftw;
     float* out;
     int E, H, W, tiles_x, tiles_per_img, nchunks;
+    // TAIL (fdn_fdsa_block): `out` is the per-tile scratch [tile][4E][8][32]; the tail's operand image, the residual, the result, its statistics
+    const float* tw;
+    const float* res;
+    float* y;
+    float* stats_out;
+    int N;
 };
 
 #ifndef FDN_FUSED_WGS
@@ -608,8 +615,11 @@ __device__ unsigned long long g_fused_trace[FT_NWG * 4 * 64];
 #else
 #define FTR(i)
 #endif
-template <int C, bool LN, bool OBF>          // OBF: the (out1|out2|out3|v_value) planes are stored as bf16
+// TAIL (round 6): 0 = the (out1|out2|out3|v_value) planes go to the [B][4E][H][W] tensor for fdn_fdsa_out; 1 = they go to this tile's own 4E x 1 KB
+// block of a scratch tensor and the workgroup runs fdn_fdsa_out's arithmetic on them itself (fdsa_tail.hpp): the whole sub-block in one launch
+template <int C, bool LN, bool OBF, int TAIL = 0>          // OBF: the (out1|out2|out3|v_value) planes are stored as bf16
 __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArgs a) {
+    static_assert(!TAIL || !OBF, "the in-kernel tail reads fp32 planes");
     // (round 4) C <= 32: the hidden tile is ONE plane per channel of (q, k, v, v_value) CELLS - the MFMA rows of a chunk are channel-major,
     // so a lane's accumulator holds whole cells - and the taps are (wq, wk, wv, wvv) cells too: a window position is one 16-byte read
     // and the four depthwise convs advance as two v_pk_fma_f32 (144 packed FMAs per thread and chunk where the three row-phase stencils
@@ -629,8 +639,10 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     const rsrc_t rx = mk_rsrc(a.x + (long)b * a.xbs, (unsigned)C * hw4);
     const rsrc_t rst = mk_rsrc(LN ? a.stats + (long)b * 2 * P : a.x, LN ? 2u * hw4 : 0u);
     constexpr unsigned OES = st_bytes<OBF>();
-    const unsigned hwo = P * OES;
-    const rsrc_t rout = mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.out) + (long)b * 4 * E * P * OES), 4u * E * hwo);
+    const unsigned hwo = TAIL ? 1024u : P * OES;                                          // bytes per output plane (TAIL: of this tile's block)
+    const float* const scr_tile = a.out + (long)t_ * 4 * E * 256;                          // (TAIL)
+    const rsrc_t rout = TAIL ? mk_rsrc(scr_tile, 4u * E * 1024u)
+                             : mk_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.out) + (long)b * 4 * E * P * OES), 4u * E * hwo);
 
 #ifdef FDN_FUSED_TRACE
     unsigned long long* trc = nullptr;
@@ -694,7 +706,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     const int row = lane & 7, px = (lane >> 3) & 3;
     const int slot = el * 4 + px;
     const int gx0 = tx0 + px * 8;
-    const unsigned opix = gx0 < W ? (unsigned)((ty0 + row) * W + gx0) * OES : OOB;
+    const unsigned opix = TAIL ? (unsigned)(row * 32 + px * 8) * 4u : gx0 < W ? (unsigned)((ty0 + row) * W + gx0) * OES : OOB;
     const float* hb = hid + el * FPL + row * FRS + px * 8;
 
     // Per-chunk operands.  A operands (packed per chunk / k-step / lane by fdn_fdsa_pack, last k-step = the bias row against
@@ -993,6 +1005,62 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         // (measured: an explicit s_waitcnt vmcnt(0) here - what a scratch reload implies - costs 1.8 % at C = 32, 1 % at C = 64: profiles/r05_l_fused64_ab.txt)
         // (the next chunk's row phase rewrites S behind the barrier at the top of the loop, i.e. after every thread has finished these reads)
     }
+    if constexpr (TAIL == 1) {
+        // ---- the tail, on this workgroup's own planes (fdsa_tail.hpp).  `hid` is dead behind the last chunk's third barrier: the operand image
+        // (gamma | beta | transposed project_out) goes global -> LDS directly, no registers; its arrival, and every store of the planes, is what
+        // vmcnt(0) waits for; behind the barrier the planes are in L2 (or beyond), visible to the sc1 loads of every wave of this workgroup
+        constexpr int SH = 19;
+        constexpr int NBLK = tl_image_floats(SH, 1) / 256;
+#ifdef FDN_FUSED_TRACE
+        if (trc) trc[40] = __builtin_amdgcn_s_memtime();
+#endif
+        const rsrc_t rtw = mk_rsrc(a.tw, (unsigned)NBLK * 1024u);
+#pragma unroll
+        for (int i = 0; i < (NBLK + 3) / 4; ++i) {
+            const int blk = __builtin_amdgcn_readfirstlane(wave + 4 * i);
+            if (blk < NBLK)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rtw, (__attribute__((address_space(3))) void*)(hid + blk * 256), 16, (unsigned)(blk * 1024 + lane * 16), 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef FDN_FUSED_TRACE
+        if (trc) trc[41] = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();
+#ifdef FDN_FUSED_TRACE
+        if (trc) trc[42] = __builtin_amdgcn_s_memtime();
+#endif
+        TailIo io;
+        io.scr = scr_tile;
+        io.res = a.res ? a.res + (long)b * a.N * P : nullptr;
+        io.y = a.y + (long)b * a.N * P;
+        io.stats_out = a.stats_out ? a.stats_out + (long)b * 2 * P : nullptr;
+        io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
+#ifdef FDN_FUSED_TRACE
+        fdsa_tail_px2<SH>(io, hid, trc);
+#else
+        fdsa_tail_px2<SH>(io, hid);
+#endif
+    }
+}
+
+// fdn_fdsa_tail_pack: project_out [N][3E] + gamma3 / beta3 [3E] -> the tail's LDS image (fdsa_tail.hpp: gamma [3][E2] | beta [3][E2] | Wl [3][E2][WS])
+__global__ void fdsa_tail_pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ img,
+                                      int E, int N, int SH, int MT, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int E2 = 2 * SH, WS = MT * 32 + 1;
+    float v = 0.f;
+    if (i < 6 * E2) {
+        const int j = i < 3 * E2 ? i : i - 3 * E2;
+        const int g = j / E2, e = j - g * E2;
+        if (e < E) v = (i < 3 * E2 ? gamma : beta)[g * E + e];
+    } else if (i < 6 * E2 + 3 * E2 * WS) {
+        const int j = i - 6 * E2;
+        const int k = j / WS, n = j - k * WS;
+        const int g = k / E2, e = k - g * E2;
+        if (n < N && e < E) v = w[(long)n * 3 * E + g * E + e];
+    }
+    img[i] = v;
 }
 
 // fdn_fdsa_pack: [4E][C] weights (+ LayerNorm gamma / beta of the input) -> per (chunk, slot, lane) 16-byte A operands of
@@ -1149,6 +1217,66 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
         default: return FDN_ERR_UNSUPPORTED;
     }
 #undef FDN_FUSED_CASE
+    fdn_note_bf16_launch();
+    return fdn_launch_status();
+}
+
+// ---- the FDSA sub-block in one launch: fdn_fdsa_fused with fdn_fdsa_out's arithmetic run by the producing workgroup (fdsa_tail.hpp) ----
+static int fdsa_tail_form(int C, int E, int N, int* sh, int* mt) {      // 0 = no in-kernel tail for this width
+    if ((C == 24 || C == 32) && E <= 38 && N <= 32) { *sh = 19; *mt = 1; return 1; }
+    return 0;
+}
+extern "C" long fdn_fdsa_tail_pack_floats(int C, int E, int N) {
+    int sh, mt;
+    return fdsa_tail_form(C, E, N, &sh, &mt) ? tl_image_floats(sh, mt) : 0;
+}
+extern "C" long fdn_fdsa_scratch_floats(int B, int E, int H, int W) {
+    if (B <= 0 || E <= 0 || H <= 0 || W <= 0 || H % 8) return 0;
+    return (long)B * (H / FT_H) * cdiv(W, FT_W) * 4 * E * 256;
+}
+extern "C" int fdn_fdsa_tail_pack(const float* w, const float* gamma3, const float* beta3, float* img, int C, int E, int N, fdn_stream_t stream) {
+    FDN_CHECK_ARG(w && gamma3 && beta3 && img && E > 0 && N > 0);
+    int sh, mt;
+    if (!fdsa_tail_form(C, E, N, &sh, &mt)) return FDN_ERR_UNSUPPORTED;
+    const int total = tl_image_floats(sh, mt);
+    hipLaunchKernelGGL(fdsa_tail_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma3, beta3, img, E, N, sh, mt, total);
+    return fdn_launch_status();
+}
+extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
+                                   const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, int B, int C,
+                                   int E, int H, int W, fdn_stream_t stream) {
+    FDN_CHECK_ARG(x && wpk && dw_w && fft_w && tail_img && out && scratch && B > 0 && E > 0 && H > 0 && W > 0);
+    FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0);
+    FDN_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(stats_out) |
+                    reinterpret_cast<uintptr_t>(scratch) | reinterpret_cast<uintptr_t>(tail_img)) & 15) == 0);
+    FDN_CHECK_ARG(out != x);                                                     // the result must not overwrite x: neighbouring tiles read its halo
+    FDN_CHECK_ARG(4ull * (C + 40) * H * W < 0x80000000ull);                      // 32-bit byte offsets per image (x, res / out rows n + 4 kh)
+    if (fdn_matrix_pipe_f32()) return FDN_ERR_UNSUPPORTED;
+    int sh, mt;
+    const int form = fdsa_tail_form(C, E, C, &sh, &mt);
+    if (!form || W % 2) return FDN_ERR_UNSUPPORTED;
+    FusedArgs a;
+    a.x = x; a.xbs = xbs; a.stats = stats; a.wpk = wpk; a.dww = dw_w; a.fftw = fft_w; a.out = scratch;
+    a.E = E; a.H = H; a.W = W;
+    a.tiles_x = cdiv(W, FT_W);
+    a.tiles_per_img = a.tiles_x * (H / FT_H);
+    a.nchunks = (E + FEG - 1) / FEG;
+    a.tw = tail_img; a.res = res; a.y = out; a.stats_out = stats_out; a.N = C;
+    const long total = (long)B * a.tiles_per_img;
+    FDN_CHECK_ARG(total < 0x7fffffffL);
+    const dim3 grid((unsigned)total), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define FDN_FUSED_TAIL_CASE(CC, TT)                                                                          \
+    case CC:                                                                                                \
+        if (stats) hipLaunchKernelGGL((fdsa_fused_kernel<CC, true, false, TT>), grid, block, 0, s, a);      \
+        else hipLaunchKernelGGL((fdsa_fused_kernel<CC, false, false, TT>), grid, block, 0, s, a);           \
+        break;
+    switch (C) {
+        FDN_FUSED_TAIL_CASE(24, 1)
+        FDN_FUSED_TAIL_CASE(32, 1)
+        default: return FDN_ERR_UNSUPPORTED;
+    }
+#undef FDN_FUSED_TAIL_CASE
     fdn_note_bf16_launch();
     return fdn_launch_status();
 }

@@ -37,7 +37,7 @@ class FdnHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 14         # include/fdn_hip.h: bumped on any signature change
+ABI_VERSION = 15         # include/fdn_hip.h: bumped on any signature change
 
 
 def lib_path():

@@ -261,6 +261,47 @@ def fdsa_fused(x, stats, wpk, dw_w, fft_w, out_dtype=torch.float32):
     return out
 
 
+FDSA_TAIL = True            # (round 6) levels 1-2: fdn_fdsa_fused_tail - the producing workgroup runs fdn_fdsa_out's arithmetic on its own tile (one launch, bit-identical)
+_fdsa_scratch = {}          # (device, floats) -> scratch tensor of fdn_fdsa_fused_tail: one per device and size, shared by every block (one stream per GPU)
+
+
+def fdsa_tail_pack(w_out, gamma3, beta3, C):
+    """project_out [N, 3E(,1,1)] + norm1..3 -> the LDS operand image of fdn_fdsa_fused_tail's in-kernel tail; None = no form for this width."""
+    N = w_out.shape[0]
+    E = w_out.numel() // N // 3
+    n = lib().fdn_fdsa_tail_pack_floats(C, E, N)
+    if n <= 0:
+        return None
+    img = torch.empty(n, device=w_out.device, dtype=torch.float32)
+    check(lib().fdn_fdsa_tail_pack(_flat(w_out.reshape(N, 3 * E), "w_out"), _flat(gamma3, "gamma3"), _flat(beta3, "beta3"), _flat(img, "img"),
+                                   C, E, N, stream()), "fdn_fdsa_tail_pack")
+    return img
+
+
+def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=False):
+    """x [B,C,H,W] -> res + project_out(norm1..3(FDSA core(LN(x))) * v_value) in ONE launch (fdn_fdsa_fused_tail), bit-identical to
+    fdsa_fused + fdsa_out.  Returns None when the library has no form for the shape."""
+    B, C, H, W = x.shape
+    E = dw_w.shape[0] // 4
+    ptr, xbs = _planes(x, "x")
+    n = lib().fdn_fdsa_scratch_floats(B, E, H, W)
+    key = (str(x.device), n)
+    scr = _fdsa_scratch.get(key)
+    if scr is None:
+        scr = _fdsa_scratch[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
+    st = torch.empty((B, 1, 2, H * W), device=x.device, dtype=torch.float32) if want_stats else None
+    rc = lib().fdn_fdsa_fused_tail(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), _flat(wpk, "wpk"), _flat(dw_w, "dw_w"), _flat(fft_w, "fft_w"),
+                                   _flat(tail_img, "tail_img"), _flat(res, "res"), _flat(out, "out"), _flat(st, "stats_out"), _flat(scr, "scratch"),
+                                   B, C, E, H, W, stream())
+    if rc == 4:
+        return None
+    check(rc, "fdn_fdsa_fused_tail")
+    if want_stats:
+        out._fdn_stats = st
+    return out
+
+
 FDSA_FULL = False           # True: the whole FDSA sub-block in one launch (fdn_fdsa_full) for C <= FDSA_FULL_MAX_C; False: fdn_fdsa_fused + fdn_fdsa_out
 FDSA_FULL_MAX_C = 32        # measured (tools/ab_fdsa_full.py, B = 8 720p shapes): one launch 3.52 against 3.77 ms at C = 32 and 2.89 against 2.93 at
                             # C = 24 (8 x 16 tiles, 8-channel chunks); at C = 48 / 64 (8 x 8 tiles, 16-channel chunks) it loses, 2.63 against 2.25 ms

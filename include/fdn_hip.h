@@ -156,6 +156,21 @@ int fdn_fdsa_full_pack(const float* w_hidden, const float* gamma, const float* b
 int fdn_fdsa_full(const float* x, long xbs, const float* stats, const void* wpk, const float* dw_w, const float* fft_w,
                   const float* res, float* out, float* stats_out, int B, int C, int E, int H, int W, fdn_stream_t stream);
 
+/* The FDSA sub-block in one launch WITHOUT new arithmetic (round 6; FDN_arch.py:575-639, the LayerNorm of :668 in front, the residual of :671
+ * behind): fdn_fdsa_fused's kernel, whose workgroup writes the (out1|out2|out3|v_value) planes of its 8 x 32 tile tile-contiguous into `scratch`,
+ * drains its stores, meets at a barrier and then runs fdn_fdsa_out's arithmetic on them itself (L2 / Infinity-Cache read-back of its own bytes:
+ * no second launch, no HBM read of the hand-off).  Results equal fdn_fdsa_fused + fdn_fdsa_out bit for bit.
+ * fdn_fdsa_tail_pack: project_out w_out [N][3E], gamma3 / beta3 [3E] -> img (fdn_fdsa_tail_pack_floats(C, E, N) floats; 0 = no in-kernel tail
+ *   for this width).  fdn_fdsa_scratch_floats(B, E, H, W): floats of `scratch` ([B * tiles][4E][8][32]).
+ * fdn_fdsa_fused_tail: x, xbs, stats, wpk, dw_w, fft_w as fdn_fdsa_fused; res [B][C][H][W] or NULL (may be x); out [B][C][H][W] (must not be x);
+ *   stats_out [B][2][P] or NULL.  C in {24, 32} with E <= 38, W even; anything else (and fdn_set_matrix_pipe(1)) returns FDN_ERR_UNSUPPORTED. */
+long fdn_fdsa_tail_pack_floats(int C, int E, int N);
+long fdn_fdsa_scratch_floats(int B, int E, int H, int W);
+int fdn_fdsa_tail_pack(const float* w_out, const float* gamma3, const float* beta3, float* img, int C, int E, int N, fdn_stream_t stream);
+int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
+                        const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, int B, int C, int E,
+                        int H, int W, fdn_stream_t stream);
+
 /* FDSA tail in one launch (FDN_arch.py:633-639 and the residual add of :671): norm1/2/3 over the E channels
  * of out1|out2|out3, times v_value, project_out (3E -> N) + res, and (optionally) the channel LayerNorm
  * statistics of the result.  o [B][4E][P] as written by fdn_fdsa_core; w [N][3E]; gamma3,beta3 [3E];

@@ -14,6 +14,9 @@ import numpy as np, torch
 import fdn_hip
 fdn_hip._LIB_PATH = os.path.abspath(sys.argv[1])
 from fdn_hip import ops
+TAIL = "--tail" in sys.argv          # (round 6) fdn_fdsa_fused_tail: the tail's stamps 40..46 (loop exit, stores drained, barrier, group 0 normalised = its data arrived,
+if TAIL:                             #  group 0's MFMAs issued, group 2's MFMAs issued, epilogue stores issued); E <= 40 only (five chunks)
+    sys.argv.remove("--tail")
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 736
 W = int(sys.argv[4]) if len(sys.argv) > 4 else 1280
@@ -35,7 +38,13 @@ for it in range(3):
     lib.fdn_debug_fused_trace_clear()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    out = ops.fdsa_fused(x, stats, wpk, dw, fw)
+    if TAIL:
+        gt = torch.Generator().manual_seed(2)
+        wo = (torch.randn(C, 3 * E, generator=gt) / (3 * E) ** .5).to(dev)
+        img = ops.fdsa_tail_pack(wo, torch.ones(3 * E, device=dev), torch.zeros(3 * E, device=dev), C)
+        out = ops.fdsa_fused_tail(x, stats, wpk, dw.reshape(4 * E, 1, 3, 3), fw, img, res=x, want_stats=True)
+    else:
+        out = ops.fdsa_fused(x, stats, wpk, dw, fw)
     e1.record()
     torch.cuda.synchronize()
 print("kernel time %.3f ms" % e0.elapsed_time(e1))
@@ -55,6 +64,14 @@ print("%-34s %10s %10s %10s %10s" % ("interval (clocks, mean per chunk)", "wave 
 for i, n in enumerate(names):
     print("%-34s %10.0f %10.0f %10.0f %10.0f" % ((n,) + tuple(d[:, wv, :, i].mean() for wv in range(4))))
 print("%-34s %10.0f %10.0f %10.0f %10.0f" % (("chunk turnaround",) + tuple(gap[:, wv].mean() for wv in range(4))))
+if TAIL:
+    tl = t[ok][:, :, 40:47]
+    tn = ["loop exit -> stores drained (vmcnt 0)", "barrier", "loads -> group 0 normalised", "group 0 MFMAs issued", "groups 1-2 (loads hidden?) issued", "epilogue (residual, stores, stats)"]
+    dt = np.diff(tl, axis=2)
+    print("tail: last chunk stamp -> loop exit %.0f clocks" % (tl[:, :, 0] - st[:, :, -1, 7]).mean())
+    for i, n in enumerate(tn):
+        print("%-40s %10.0f %10.0f %10.0f %10.0f" % ((n,) + tuple(dt[:, wv, i].mean() for wv in range(4))))
+    print("tail total %.0f clocks of a wave life of %.0f" % (dt.sum(axis=2).mean(), (tl[:, :, 6] - meta[:, :, 3]).mean()))
 tot = d.sum(axis=3).mean(axis=(0, 2))
 bar = d[:, :, :, [1, 3, 5]].sum(axis=3).mean(axis=(0, 2))
 print("per chunk total", np.round(tot), " at barriers", np.round(bar), " share", np.round(bar / tot, 3))
