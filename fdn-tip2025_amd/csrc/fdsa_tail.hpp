@@ -161,4 +161,191 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
     TLTR(6)
 }
 
+// Level-2 form (E <= 2 SH <= 76, N <= 64): one pixel per lane, a wave takes its two tile rows one after the other; project_out on the bf16 matrix pipe
+// (three exact bf16 parts per operand, six products: fp32 arithmetic).  Mirrors fdsa_out_vec_kernel<38, 2, false, false, 1, 8, true> - the same sums, the
+// same operand cuts, the same MFMA order - so the result equals fdn_fdsa_fused + fdn_fdsa_out bit for bit.
+// Operand image (fdn_fdsa_tail_pack): [gamma 3 E2 | pad to 256 floats][beta 3 E2 | pad to 256][Wp [3][NQ][MT][part][64 lanes] 16-byte A operands].
+// The workgroup's 80 KB of LDS hold groups 0 and 1 (one in the dead hidden tile, one in the dead spectra: two arrays, so the compiler keeps the waits
+// of the two LDS-DMA batches apart); group 2's operands are read from the image itself (30 KB, L1 / L2 hits: the data loads bypass L1).
+#ifndef FDN_TAIL_CALL
+#define FDN_TAIL_CALL 0          // 1: the level-2 tail is a real function (its register allocation and the chunk loop's do not meet); 0: inlined
+#endif
+#if FDN_TAIL_CALL
+#define FDN_TAIL_FN __attribute__((noinline))
+#else
+#define FDN_TAIL_FN __forceinline__
+#endif
+typedef __attribute__((address_space(3))) const float* lds_cf;
+typedef __attribute__((address_space(3))) const fdn_u32x4* lds_cu4;
+// (a non-inlined device function receives its arguments in vector registers: the wave-uniform ones are made scalar again here)
+template <typename Tp>
+__device__ __forceinline__ Tp* tl_uniform_ptr(Tp* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<Tp*>(((unsigned long long)hi << 32) | lo);
+}
+template <int SH, int MT>
+__device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb, lds_cu4 W0, lds_cu4 W1, const float* gimg_,
+                                              unsigned long long* trc = nullptr) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    TailIo io;
+    io.scr = tl_uniform_ptr(io_.scr); io.res = tl_uniform_ptr(io_.res); io.y = tl_uniform_ptr(io_.y); io.stats_out = tl_uniform_ptr(io_.stats_out);
+    io.E = __builtin_amdgcn_readfirstlane(io_.E); io.N = __builtin_amdgcn_readfirstlane(io_.N); io.W = __builtin_amdgcn_readfirstlane(io_.W);
+    io.ty0 = __builtin_amdgcn_readfirstlane(io_.ty0); io.tx0 = __builtin_amdgcn_readfirstlane(io_.tx0); io.P = __builtin_amdgcn_readfirstlane(io_.P);
+    const float* gimg = tl_uniform_ptr(gimg_);
+    constexpr int E2 = 2 * SH, NQ = (SH + 7) / 8;
+    const int E = io.E, N = io.N;
+    const unsigned P = io.P, P4 = P * 4u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kh = lane >> 5, ln = lane & 31;
+    constexpr unsigned PI = 1024u;
+    const trsrc_t rg[3] = {tl_rsrc(io.scr, (unsigned)E * PI), tl_rsrc(io.scr + (long)E * 256, (unsigned)E * PI),
+                           tl_rsrc(io.scr + (long)2 * E * 256, (unsigned)E * PI)};
+    const trsrc_t rv = tl_rsrc(io.scr + (long)3 * E * 256, (unsigned)E * PI);
+    const trsrc_t rw2 = tl_rsrc(gimg + 512 + 2 * NQ * MT * 3 * 64 * 4, (unsigned)(NQ * MT * 3 * 64) * 16u);      // group 2's operands
+    const float invE = 1.0f / (float)E;
+    const unsigned nb4 = (unsigned)N * P4;
+    const trsrc_t ro = tl_rsrc(io.y, nb4);
+    const trsrc_t rr = tl_rsrc(io.res ? io.res : io.y, io.res ? nb4 : 0u);
+    const bool ok = io.tx0 + ln < io.W;
+
+    float vv[SH], buf[2][SH];
+    auto voff_of = [&](int rnd) { return kh * PI + (unsigned)((2 * wave + rnd) * 32 + ln) * 4u; };
+    {
+        const unsigned voff = voff_of(0);
+        unsigned PIl = PI;
+        asm volatile("" : "+s"(PIl));
+#pragma unroll
+        for (int s = 0; s < SH; ++s) {
+            vv[s] = tl_load1(rv, voff, (unsigned)(2 * s) * PIl);
+            buf[0][s] = tl_load1(rg[0], voff, (unsigned)(2 * s) * PIl);
+        }
+    }
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        // (as in fdsa_out_vec_kernel: the plane offsets n P4 and the channel-range predicates are loop invariants the compiler would otherwise park in
+        //  ~190 scalar registers / vector lanes; opaque per-row copies keep each one s_mul / one compare beside its use)
+        unsigned P4l = P4;
+        asm volatile("" : "+s"(P4l));
+        int khl = kh;
+        asm volatile("" : "+v"(khl));
+        const unsigned voff = voff_of(rnd);
+        const unsigned pix = (unsigned)((io.ty0 + 2 * wave + rnd) * io.W + io.tx0 + ln);
+        const unsigned vo = ok ? (4u * kh * P + pix) * 4u : 0x80000000u;
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        float rres[MT][16];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            float* cur = buf[(rnd + g) & 1];
+            float* nxt = buf[(rnd + g + 1) & 1];
+            unsigned PIl = PI;                      // (the plane offsets 2 s PI are loop invariants too: a scalar register each unless rebuilt beside the load)
+            asm volatile("" : "+s"(PIl));
+            if (g < 2) {
+#pragma unroll
+                for (int s = 0; s < SH; ++s) nxt[s] = tl_load1(rg[g + 1], voff, (unsigned)(2 * s) * PIl);
+            }
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < SH; ++s) m += cur[s];
+            m = tl_xsum32(m) * invE;
+            float q = 0.f;
+#pragma unroll
+            for (int s = 0; s < SH; ++s) {
+                const float dl = cur[s] - m;
+                q += (2 * s + khl < E) ? dl * dl : 0.f;
+            }
+            const float rs = tl_rsqrt_eps(tl_xsum32(q) * invE);
+#pragma unroll
+            for (int s = 0; s < SH; ++s) {
+                asm volatile("" ::: "memory");
+                const int e = 2 * s + kh;
+                cur[s] = ((cur[s] - m) * rs * tg[g * E2 + e] + tb[g * E2 + e]) * vv[s];      // norm_g(out_g) * v_value  :633-638
+            }
+            if (g == 0 && rnd == 0) { TLTR(3) }
+            if (g == 2 && rnd == 0) {          // the second row's v_value and group 0: v_value was last used just above, the idle set held group 1
+                const unsigned voff1 = voff_of(1);
+#pragma unroll
+                for (int s = 0; s < SH; ++s) {
+                    vv[s] = tl_load1(rv, voff1, (unsigned)(2 * s) * PIl);
+                    nxt[s] = tl_load1(rg[0], voff1, (unsigned)(2 * s) * PIl);
+                }
+            }
+#pragma unroll
+            for (int q8 = 0; q8 < NQ; ++q8) {
+                fdn_u32x4 bx[3];
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    const int s0 = 8 * q8 + 2 * dd, s1 = s0 + 1;
+                    unsigned p1, p2, p3;
+                    fdn_split3(s0 < SH ? cur[s0 < SH ? s0 : 0] : 0.f, s1 < SH ? cur[s1 < SH ? s1 : 0] : 0.f, p1, p2, p3);
+                    bx[0][dd] = p1, bx[1][dd] = p2, bx[2][dd] = p3;
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    fdn_u32x4 a3[3];
+                    if (g < 2) {
+                        lds_cu4 wp = (g == 0 ? W0 : W1) + ((q8 * MT + mt) * 3) * 64 + lane;
+                        a3[0] = wp[0]; a3[1] = wp[64]; a3[2] = wp[128];
+                    } else {
+                        const unsigned o = (unsigned)(((q8 * MT + mt) * 3) * 64 + lane) * 16u;
+#pragma unroll
+                        for (int part = 0; part < 3; ++part) a3[part] = __builtin_amdgcn_raw_buffer_load_b128(rw2, o, (unsigned)part * 1024u, 0);
+                    }
+                    acc[mt] = fdn_mfma_split6(a3, bx, acc[mt]);
+                }
+            }
+            if (g == 0 && rnd == 0) {
+                TLTR(4)
+                // group 1's operands were requested (LDS-DMA into the spectra's array) by all four waves behind the barrier in front of this function:
+                // every wave's share has to have landed before any wave reads them
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        if (rnd == 0) { TLTR(5) }
+        // ---- epilogue: residual (one batch), store, next LayerNorm's statistics (fdsa_out_vec_kernel's) ----
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rres[mt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vo, (unsigned)(mt * 32 + (r & 3) + 8 * (r >> 2)) * P4l, 0));      // 0 without a residual
+        float outv[MT][16];
+        float sm = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = mt * 32 + (r & 3) + 8 * (r >> 2);
+                float o = acc[mt][r];
+                o += rres[mt][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, vo, (unsigned)nrow * P4l, 0);
+                outv[mt][r] = (nrow + 4 * khl < N) ? o : 0.f;
+                sm += outv[mt][r];
+            }
+        if (io.stats_out) {
+            float sq = 0.f;
+            const float mean = tl_xsum32(sm) / (float)N;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dl = outv[mt][r] - mean;
+                    sq += (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khl < N) ? dl * dl : 0.f;
+                }
+            const float rstd = tl_rsqrt_eps(tl_xsum32(sq) / (float)N);
+            if (kh == 0) {
+                const trsrc_t rs_ = tl_rsrc(io.stats_out, 2u * P4);
+                const unsigned vs = ok ? pix * 4u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mean), rs_, vs, 0u, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstd), rs_, vs, P4, 0);
+            }
+        }
+    }
+    TLTR(6)
+}
+__host__ __device__ constexpr int tl_image_floats_px1(int SH, int MT) { return 512 + 3 * ((SH + 7) / 8) * MT * 3 * 64 * 4; }
+
 }  // namespace

@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
     __shared__ __attribute__((aligned(16))) float hid[32 * FPL + (FDN_FUSED_WGS == 1 ? 2048 : 0)];      // (A/B hook: a pad that leaves room for one workgroup per CU only)
     __shared__ __attribute__((aligned(16))) float2 S[3 * NP * PS];
     __shared__ __attribute__((aligned(16))) float wks[32 * 9];        // depthwise taps of the chunk: [kind * 8 + channel][9]; CELLS: [channel][tap][kind]
-    __shared__ float fgs[FEG * 40];                                   // fft gains of the chunk's channels: [channel][ky][kx]
+    __shared__ __attribute__((aligned(16))) float fgs[FEG * 40];      // fft gains of the chunk's channels: [channel][ky][kx]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
     const int t_ = (int)xcd_contiguous(blockIdx.x, gridDim.x);            // every XCD walks a contiguous run of tiles
@@ -1041,6 +1041,45 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         fdsa_tail_px2<SH>(io, hid);
 #endif
     }
+    if constexpr (TAIL == 2) {
+        // ---- level 2 (fdsa_tail_px1): gamma -> wks, beta -> fgs, group 0's packed operands -> hid (all dead behind the last chunk's third barrier);
+        // group 1's -> S, which the last inverse rows still read: behind the barrier
+        constexpr int SH = 38, MT = 2, NQ = (SH + 7) / 8, GB = NQ * MT * 3;           // GB: KB (= wave-level DMA instructions) per group
+        const rsrc_t rtw = mk_rsrc(a.tw, (unsigned)tl_image_floats_px1(SH, MT) * 4u);
+        auto dma = [&](const void* dst, int src_blk, int nblk, int first = -1) {          // waves take the KB blocks in turn (first: starting wave)
+            for (int i = first < 0 ? wave : (wave - first) & 3; i < nblk; i += 4) {
+                const int blk = __builtin_amdgcn_readfirstlane(i);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rtw, (__attribute__((address_space(3))) void*)(reinterpret_cast<const char*>(dst) + blk * 1024), 16,
+                                                         (unsigned)((src_blk + blk) * 1024 + lane * 16), 0, 0, 0);
+            }
+        };
+#ifdef FDN_FUSED_TRACE
+        if (trc) trc[40] = __builtin_amdgcn_s_memtime();
+#endif
+        dma(wks, 0, 1, 2);               // (waves 2 and 3 carry one block less of group 0's 30)
+        dma(fgs, 1, 1, 3);
+        dma(hid, 2, GB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef FDN_FUSED_TRACE
+        if (trc) trc[41] = __builtin_amdgcn_s_memtime();
+#endif
+        __syncthreads();
+#ifdef FDN_FUSED_TRACE
+        if (trc) trc[42] = __builtin_amdgcn_s_memtime();
+#endif
+        dma(S, 2 + GB, GB);
+        TailIo io;
+        io.scr = scr_tile;
+        io.res = a.res ? a.res + (long)b * a.N * P : nullptr;
+        io.y = a.y + (long)b * a.N * P;
+        io.stats_out = a.stats_out ? a.stats_out + (long)b * 2 * P : nullptr;
+        io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
+#ifdef FDN_FUSED_TRACE
+        fdsa_tail_px1<SH, MT>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw, trc);
+#else
+        fdsa_tail_px1<SH, MT>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw);
+#endif
+    }
 }
 
 // fdn_fdsa_tail_pack: project_out [N][3E] + gamma3 / beta3 [3E] -> the tail's LDS image (fdsa_tail.hpp: gamma [3][E2] | beta [3][E2] | Wl [3][E2][WS])
@@ -1221,14 +1260,48 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
     return fdn_launch_status();
 }
 
+// the level-2 image: [gamma 3 E2 | pad][beta 3 E2 | pad][Wp [3][NQ][MT][part][64] A operands of v_mfma_f32_32x32x16_bf16]: lane l = (n = mt 32 + (l & 31), k2 = l >> 5)
+// holds channels e = 2 (8 q + 2 d + h) + k2, d = 0..3, h = 0..1, cut into the part-th bf16 part (fdsa_out_vec_kernel's in-kernel packing, done once here)
+static __global__ void fdsa_tail_pack_px1_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ img,
+                                          int E, int N, int SH, int MT) {
+    const int E2 = 2 * SH, NQ = (SH + 7) / 8;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 512) {
+        const int j = i & 255;
+        const int g = j / E2, e = j - g * E2;
+        img[i] = (j < 3 * E2 && e < E) ? (i < 256 ? gamma : beta)[g * E + e] : 0.f;
+        return;
+    }
+    const int u = i - 512;
+    if (u >= 3 * NQ * MT * 3 * 64) return;
+    const int l = u & 63, part = (u >> 6) % 3, mt = (u / 192) % MT, q = (u / (192 * MT)) % NQ, g = u / (192 * MT * NQ);
+    const int n = mt * 32 + (l & 31), k2 = l >> 5;
+    fdn_u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        unsigned hl[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s_ = 8 * q + 2 * d + h, e = 2 * s_ + k2;
+            float x = (n < N && s_ < SH && e < E) ? w[(long)n * 3 * E + g * E + e] : 0.f;
+            for (int pp = 0; pp < part; ++pp) x -= fdn_trunc_bf16(x);
+            hl[h] = __float_as_uint(x) >> 16;
+        }
+        o[d] = hl[0] | (hl[1] << 16);
+    }
+    reinterpret_cast<fdn_u32x4*>(img + 512)[u] = o;
+}
+
 // ---- the FDSA sub-block in one launch: fdn_fdsa_fused with fdn_fdsa_out's arithmetic run by the producing workgroup (fdsa_tail.hpp) ----
 static int fdsa_tail_form(int C, int E, int N, int* sh, int* mt) {      // 0 = no in-kernel tail for this width
     if ((C == 24 || C == 32) && E <= 38 && N <= 32) { *sh = 19; *mt = 1; return 1; }
+    if ((C == 48 || C == 64) && E > 38 && E <= 76 && N > 32 && N <= 64) { *sh = 38; *mt = 2; return 2; }
     return 0;
 }
 extern "C" long fdn_fdsa_tail_pack_floats(int C, int E, int N) {
     int sh, mt;
-    return fdsa_tail_form(C, E, N, &sh, &mt) ? tl_image_floats(sh, mt) : 0;
+    const int form = fdsa_tail_form(C, E, N, &sh, &mt);
+    return form == 1 ? tl_image_floats(sh, mt) : form == 2 ? tl_image_floats_px1(sh, mt) : 0;
 }
 extern "C" long fdn_fdsa_scratch_floats(int B, int E, int H, int W) {
     if (B <= 0 || E <= 0 || H <= 0 || W <= 0 || H % 8) return 0;
@@ -1237,7 +1310,13 @@ extern "C" long fdn_fdsa_scratch_floats(int B, int E, int H, int W) {
 extern "C" int fdn_fdsa_tail_pack(const float* w, const float* gamma3, const float* beta3, float* img, int C, int E, int N, fdn_stream_t stream) {
     FDN_CHECK_ARG(w && gamma3 && beta3 && img && E > 0 && N > 0);
     int sh, mt;
-    if (!fdsa_tail_form(C, E, N, &sh, &mt)) return FDN_ERR_UNSUPPORTED;
+    const int form = fdsa_tail_form(C, E, N, &sh, &mt);
+    if (!form) return FDN_ERR_UNSUPPORTED;
+    if (form == 2) {
+        const int nthreads = 512 + (tl_image_floats_px1(sh, mt) - 512) / 4;     // 512 header floats + one thread per 16-byte operand
+        hipLaunchKernelGGL(fdsa_tail_pack_px1_kernel, dim3(cdiv(nthreads, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma3, beta3, img, E, N, sh, mt);
+        return fdn_launch_status();
+    }
     const int total = tl_image_floats(sh, mt);
     hipLaunchKernelGGL(fdsa_tail_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma3, beta3, img, E, N, sh, mt, total);
     return fdn_launch_status();
@@ -1254,7 +1333,7 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     if (fdn_matrix_pipe_f32()) return FDN_ERR_UNSUPPORTED;
     int sh, mt;
     const int form = fdsa_tail_form(C, E, C, &sh, &mt);
-    if (!form || W % 2) return FDN_ERR_UNSUPPORTED;
+    if (!form || (form == 1 && W % 2)) return FDN_ERR_UNSUPPORTED;
     FusedArgs a;
     a.x = x; a.xbs = xbs; a.stats = stats; a.wpk = wpk; a.dww = dw_w; a.fftw = fft_w; a.out = scratch;
     a.E = E; a.H = H; a.W = W;
@@ -1274,6 +1353,8 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     switch (C) {
         FDN_FUSED_TAIL_CASE(24, 1)
         FDN_FUSED_TAIL_CASE(32, 1)
+        FDN_FUSED_TAIL_CASE(48, 2)
+        FDN_FUSED_TAIL_CASE(64, 2)
         default: return FDN_ERR_UNSUPPORTED;
     }
 #undef FDN_FUSED_TAIL_CASE

@@ -6,6 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
 import torch
 import fdn_hip
+for a_ in sys.argv[1:]:
+    if a_.endswith(".so"):
+        fdn_hip._LIB_PATH = os.path.abspath(a_)          # another build of the library (tools/ab_build.sh)
+        print("library:", a_)
 from fdn_hip import ops
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 7
@@ -70,6 +74,11 @@ case(1, 32, 16, 40, time_it=False)
 case(2, 32, 24, 72, time_it=False, edge=True)
 case(1, 24, 32, 64, time_it=False)
 case(2, 32, 64, 96, time_it=False, edge=True)
+case(1, 64, 16, 40, time_it=False)
+case(2, 64, 24, 72, time_it=False, edge=True)
+case(2, 48, 32, 64, time_it=False, edge=True)
 if not small:
     case(8, 32, 736, 1280)
     case(8, 24, 400 // 8 * 8, 608)
+    case(8, 64, 368, 640)
+    case(8, 48, 200, 304)
