@@ -22,6 +22,7 @@ the CPU oracle on a bounded sample.
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -442,7 +443,137 @@ def cpu_baseline(h=256, w=256, full_720p=False):
         t720 = one()
         out["measured_736x1280"] = {"images_per_s": 1.0 / t720, "seconds": round(t720, 2), "threads": cores,
                                     "note": "one timed oracle forward of ONE padded 736x1280 image (no scaling): the CPU figure in the metric's own unit"}
+        out["measured_720p"] = out["measured_736x1280"]            # (the name VERDICT r5 item 4 uses)
     return out
+
+
+def parity_against_reference(forward, x):
+    """(BASELINE.json metric "...; PSNR vs ref") The graph that was just timed, replayed ONCE with the configs[1] fixture frame in
+    batch slot 0 (the seeded 720 x 1280 frame of tests/golden/fdn_tamed_736x1280.npz, reflect-padded; the other slots keep the bench input: samples do
+    not interact) and its `result` judged by the rule of tests/test_gpu_configs.py::test_config1_736x1280_frame_matches_reference: 64 seeded 32 x 32
+    windows against the REFERENCE's own fp32 forward on that frame (generated in the build container by tests/golden/make_golden_configs.py) and
+    against the float64 truth, every window within 4 x what fp32 is known to do at that window + 5e-8.  Nothing here reads /root/reference."""
+    import numpy as np
+    gold = os.path.join(ROOT, "tests", "golden")
+    z, z64 = np.load(os.path.join(gold, "fdn_tamed_736x1280.npz")), np.load(os.path.join(gold, "fdn_tamed_736x1280_f64.npz"))
+    if abs(float(z["tame"]) - 0.03) > 1e-6:
+        return {"skipped": "fixture weights differ from the bench's"}
+    f = torch.rand(1, 3, 720, 1280, generator=torch.Generator().manual_seed(int(z["x_seed"])))
+    f = torch.nn.functional.pad(f, (0, 0, 0, 16), mode="reflect")
+    if abs(f.double().sum().item() - float(z["x_sum64"])) > 1e-6:
+        return {"skipped": "the seeded frame is not the one the fixture was made from"}
+    xb = x.clone()
+    xb[0] = f[0].to(x.device)
+    y = forward(xb)[0:1].float().cpu()
+    ratio = getattr(forward, "ratio", None)
+    rerr = None if ratio is None else float((ratio[0:1].cpu() - torch.from_numpy(z["ratio"])).abs().max())
+    org, win, t64 = z["y_org"], torch.from_numpy(z["y_win"]).double(), torch.from_numpy(z64["y_win64"])
+    mine = torch.stack([y[0, :, y0:y0 + 32, x0:x0 + 32] for y0, x0 in org.tolist()]).double()
+    rms = lambda t: (t ** 2).mean((1, 2, 3)).sqrt()
+    e_hip, e_ref = rms(mine - t64), rms(win - t64)
+    cap = torch.maximum(torch.maximum(e_ref, torch.from_numpy(z64["y_susc"]).max(0)[0]), torch.from_numpy(z64["y_susc_noise"]).max(0)[0])
+    bad = (e_hip > 4.0 * cap + 5e-8).nonzero().flatten().tolist()
+    mse = float(((mine - win) ** 2).mean())
+    d = y.double()
+    mom = torch.from_numpy(z["y_mom"])
+    n = y.shape[2] * y.shape[3]
+    return {"frame": "tests/golden/fdn_tamed_736x1280.npz (seeded 720x1280 frame, reflect-padded; the reference's own forward, 64 windows of `result`)",
+            "graph": "the captured graph of the timed steps, fixture frame in batch slot 0",
+            "psnr_vs_reference_windows": (float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)),
+            "psnr_vs_float64_windows": 10.0 * math.log10(1.0 / float(((mine - t64) ** 2).mean())),
+            "reference_psnr_vs_float64_windows": 10.0 * math.log10(1.0 / float(((win - t64) ** 2).mean())),
+            "windows": 64, "windows_failing": len(bad), "failing": bad[:8], "rule": "err(HIP, f64)[w] <= 4 max(err(ref fp32, f64)[w], susceptibility[w]) + 5e-8",
+            "median_window_err_vs_f64": {"hip": float(e_hip.median()), "reference": float(e_ref.median())},
+            "mean_abs_err_per_channel": float(((d.sum((0, 2, 3)) - mom[0]).abs() / n).max()),
+            "ratio_abs_err": rerr, "ok": (not bad) and (rerr is None or rerr <= 5e-6)}
+
+
+class GpuSensors:
+    """Shader clock and socket power of the benchmarked GPU while the timed steps run, sampled from sysfs by a host thread every 50 ms (hwmon
+    `freq1_input` in Hz, `power1_average` / `power1_input` in microwatts; amdgpu's pp_dpm_sclk as a fall-back for the clock).  Read-only, no tool
+    is started, nothing is set.  The package runs at its power cap under these kernels: box-to-box and loop-vs-step
+    differences show up here."""
+
+    def __init__(self, device_index=0):
+        import glob
+        self.freq = self.power = self.dpm = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        bus = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        pick = [c for c in cards if bus and bus in os.path.realpath(c)] or cards
+        for c in pick:
+            hw = sorted(glob.glob(os.path.join(c, "hwmon", "hwmon*")))
+            for h in hw:
+                f = os.path.join(h, "freq1_input")
+                pw = [q for q in (os.path.join(h, "power1_average"), os.path.join(h, "power1_input")) if os.path.isfile(q)]
+                if os.path.isfile(f) or pw:
+                    self.freq = f if os.path.isfile(f) else None
+                    self.power = pw[0] if pw else None
+                    self.dpm = os.path.join(c, "pp_dpm_sclk") if os.path.isfile(os.path.join(c, "pp_dpm_sclk")) else None
+                    self.card = c
+                    break
+            if self.freq or self.power:
+                break
+        self.samples = []
+        self._stop = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            return open(path).read()
+        except Exception:
+            return None
+
+    def _one(self):
+        mhz = w = None
+        t = self._read(self.freq) if self.freq else None
+        if t and t.strip().isdigit():
+            mhz = int(t) / 1e6
+        elif self.dpm:
+            t = self._read(self.dpm)
+            if t:
+                cur = [ln for ln in t.splitlines() if ln.rstrip().endswith("*")]
+                if cur:
+                    mhz = float("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit() or ch == "."))
+        t = self._read(self.power) if self.power else None
+        if t and t.strip().isdigit():
+            w = int(t) / 1e6
+        return mhz, w
+
+    def __enter__(self):
+        import threading
+        self.samples = []
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._one())
+                self._stop.wait(0.05)
+        self._th = threading.Thread(target=loop, daemon=True)
+        if self.freq or self.power or self.dpm:
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._th.is_alive():
+            self._th.join()
+
+    def summary(self):
+        f = [a for a, _ in self.samples if a]
+        p = [b for _, b in self.samples if b]
+        if not f and not p:
+            return {"available": False, "note": "no readable hwmon clock / power file for this GPU"}
+        out = {"available": True, "samples": len(self.samples), "source": "sysfs hwmon, 50 ms period, host thread, over the timed steps"}
+        if f:
+            out.update({"clock_mhz_mean": sum(f) / len(f), "clock_mhz_min": min(f), "clock_mhz_max": max(f)})
+        if p:
+            out.update({"power_w_mean": sum(p) / len(p), "power_w_max": max(p)})
+        return out
 
 
 def free_port():
@@ -520,9 +651,13 @@ def main():
                     "fdn_fdsa_fused + fdn_fdsa_out (DESIGN.md section 4: built, correct, not the default)")
     ap.add_argument("--fdsa-pair", action="store_true", help="A/B: the FDSA sub-blocks of levels 1-2 as fdn_fdsa_fused + fdn_fdsa_out (two launches, the 4E-plane hand-off "
                     "through HBM: the round-5 route) instead of fdn_fdsa_fused_tail")
+    ap.add_argument("--no-tail-pin", action="store_true", help="A/B: the FDFFN project_in of level 1 as its own fdn_conv1x1 launch instead of inside fdn_fdsa_fused_tail")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short side measurements of BASELINE.json configs[2] (1080p B = 4 bf16 storage) "
                     "and configs[4] (LPNet alone) that the default headline run appends as `other_configs`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the replay of the timed graph on the configs[1] fixture frame (`parity` in the JSON line)")
+    ap.add_argument("--no-cpu-720p", action="store_true", help="cpu_baseline without the ONE real 736 x 1280 oracle forward (~3 minutes of host time) that the "
+                    "default headline run includes")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU / gloo rehearsal of the launcher, sharding, scatter / gather and timing protocol with a stand-in "
@@ -582,6 +717,7 @@ def main():
         fdn_hip.set_storage_dtype(a.dtype)
         fdn_hip.ops.FDSA_FULL = bool(a.fdsa_full)
         fdn_hip.ops.FDSA_TAIL = not a.fdsa_pair
+        fdn_hip.ops.FDSA_TAIL_PIN = not a.no_tail_pin
         if a.narrow_pipe:
             fdn_hip.set_matrix_pipe("bf16-narrow")
         fdn_hip.ops.SPECTRAL_MLP_FUSED = not a.unfused_mlps
@@ -656,7 +792,13 @@ def main():
 
     for _ in range(a.warmup):
         step(sg)
-    dt = timed(sg, a.steps)                                            # THE measurement: exactly K steps
+    sensors = None
+    if rank == 0 and not a.dry_run:
+        sensors = GpuSensors(local_rank)
+        with sensors:
+            dt = timed(sg, a.steps)                                    # THE measurement: exactly K steps
+    else:
+        dt = timed(sg, a.steps)
     host_issue_ms = host_s[0] / a.steps * 1e3
     dt_nosg = None
     if sg:                                                             # beside it: the same K steps without the collectives
@@ -665,51 +807,80 @@ def main():
         ok = all(torch.equal(o, forward(i)) for o, i in zip(root_out, root_in))
         assert ok, "dry run: gathered outputs differ from the root's own forward"
 
-    roof = top = entries = None
-    prof = None
-    if rank == 0 and not a.no_roofline and not a.dry_run:
+    parity = None
+    if (rank == 0 and not a.dry_run and a.graph and a.config == "fdn" and a.variant == "lolblur" and a.dtype == "f32" and a.streams == 1
+            and (a.height, a.width) == (720, 1280) and not a.no_parity):
+        parity = parity_against_reference(forward, x)
+
+    default_routing = not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
+
+    def roofline_of(xin, dtype, hw, lpnet_only=False):
+        """(roofline of the dominant individual kernel, top 3, the matching committed PMC profile or None) from two instrumented single-stream
+        forwards of `xin` in the current storage mode."""
         agg = None
         for _ in range(2):                                          # the first instrumented pass also pays one-off host costs
             with KernelTimer() as kt:
                 with torch.no_grad():
-                    if a.config == "lpnet":
-                        lp(x)
+                    if lpnet_only:
+                        lp(xin)
                     else:
-                        net(x, ratio_i=lp(x), device=dev)           # single stream: events bracket each launch
+                        net(xin, ratio_i=lp(xin), device=dev)       # single stream: events bracket each launch
             cur = kt.summary()
             agg = cur if agg is None else {k: (v if v[2] <= agg.get(k, v)[2] else agg[k]) for k, v in cur.items()}
         total_ms = sum(v[2] for v in agg.values())
         # figures taken from the committed PMC passes describe the DEFAULT routing of the code they were recorded on: with an A/B route
-        # switched on (--fdsa-full, --narrow-pipe) the kernels differ, so nothing is borrowed from them
-        default_routing = not (a.fdsa_full or a.fdsa_pair or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
-        prof = matching_profile([B, a.height, a.width], a.dtype) if (a.config == "fdn" and a.variant == "lolblur" and default_routing) else None
-        traffic = {k: v["hbm_bytes_per_launch"] for k, v in prof["groups"].items()} if prof else {}
+        # switched on (--fdsa-pair, --narrow-pipe) the kernels differ, so nothing is borrowed from them
+        prof_ = matching_profile([xin.shape[0], hw[0], hw[1]], dtype) if (not lpnet_only and a.variant == "lolblur" and default_routing) else None
+        traffic = {k: v["hbm_bytes_per_launch"] for k, v in prof_["groups"].items()} if prof_ else {}
         ranked = sorted(agg.items(), key=lambda kv: -kv[1][2])
-        top = []
+        top_ = []
         for key, rec in ranked[:3]:
             r_ = kernel_roofline(key, rec, traffic)
             r_["share_of_step"] = rec[2] / total_ms
-            g_ = prof["groups"].get(key) if prof else None
+            g_ = prof_["groups"].get(key) if prof_ else None
             if g_ and "simd_time_frac" in g_:                       # what actually bounds it: issue time of the two pipes (committed PMC passes)
                 r_["simd_busy_from_profile"] = {"valu": round(g_["simd_time_frac"]["valu"], 3), "mfma": round(g_["simd_time_frac"]["mfma"], 3),
-                                                "profile": prof["file"], "profile_avg_ms": g_["avg_ms"]}
-            top.append(r_)
-        roof = dict(top[0])                                         # the dominant INDIVIDUAL kernel
-        entries = {}
+                                                "profile": prof_["file"], "profile_avg_ms": g_["avg_ms"]}
+            top_.append(r_)
+        roof_ = dict(top_[0])                                       # the dominant INDIVIDUAL kernel
+        ent = {}
         for key, rec in agg.items():
-            entries[rec[0]] = entries.get(rec[0], 0.0) + rec[2]
-        roof["single_stream_forward_ms"] = total_ms
-        roof["by_entry_point_ms"] = {k: round(v, 3) for k, v in sorted(entries.items(), key=lambda kv: -kv[1])}
+            ent[rec[0]] = ent.get(rec[0], 0.0) + rec[2]
+        roof_["single_stream_forward_ms"] = total_ms
+        roof_["by_entry_point_ms"] = {k: round(v, 3) for k, v in sorted(ent.items(), key=lambda kv: -kv[1])}
+        return roof_, top_, prof_
+
+    def whole_path_of(dtype, P_, batch, ips_per_gpu, step_s, prof_):
+        """B_alg = 7,256 elements per padded pixel x sizeof(elem) - 4 bytes in fp32, 2 in the bf16-storage configuration"""
+        eb = 4.0 if dtype == "f32" else 2.0
+        wp = {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * eb * P_ * ips_per_gpu / (PEAK_HBM_GBS * 1e9),
+              "mfma_f32_frac": F_ALG_PER_PX * P_ * ips_per_gpu / (PEAK_F32_MFMA_TF * 1e12)}
+        if prof_ is not None:
+            # SURVEY 8(d) `roofline.measured`: the bytes a step moves ACCORDING TO THE COMMITTED PMC PASSES of this shape (memory-side read
+            # requests by size + write requests, one forward of B images, recorded on the code of that profile - named in `profile` /
+            # `profile_commit`, NOT measured in this run) over THIS run's step time, against 8 TB/s
+            moved = (prof_["total"]["read_GB"] + prof_["total"]["write_GB"]) * 1e9
+            wp.update({"hbm_from_committed_profile_frac": moved / step_s / (PEAK_HBM_GBS * 1e9),
+                       "hbm_from_committed_profile_GB_per_step": moved / 1e9,
+                       "hbm_from_committed_profile_over_algorithmic": moved / (B_ALG_ELEMS_PER_PX * eb * P_ * batch),
+                       "profile": prof_["file"], "profile_commit": prof_.get("commit")})
+        return wp
+
+    roof = top = None
+    prof = None
+    if rank == 0 and not a.no_roofline and not a.dry_run:
+        roof, top, prof = roofline_of(x, a.dtype, (a.height, a.width), lpnet_only=a.config == "lpnet")
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.dry_run:
-        cpu = cpu_baseline(full_720p=a.cpu_720p)
+        headline_default = (a.config == "fdn" and a.variant == "lolblur" and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8))
+        cpu = cpu_baseline(full_720p=a.cpu_720p or (headline_default and not a.no_cpu_720p))
 
     # BASELINE.json names two more single-GPU configurations: they are measured here, briefly, in the same process and by the same protocol (captured
     # graph, untimed warm-up, K steps between synchronisations), so that every run of the headline command records them too (VERDICT r4, row g)
     other = None
     if (rank == 0 and world == 1 and not a.dry_run and not a.no_other_configs and a.config == "fdn" and a.variant == "lolblur" and a.graph
-            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.fdsa_pair or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
+            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
         from fdn_hip.pipeline import GraphedStep
 
         def side(fn, xin, steps=3):
@@ -727,9 +898,13 @@ def main():
         try:
             fdn_hip.set_storage_dtype("bf16")
             x2 = make_input(4, 1080, 1920, dev, seed=2000)
-            ms2 = side(GraphedStep(net, lp, 1), x2)
+            ms2 = side(GraphedStep(net, lp, 1), x2, steps=10)
             other["configs[2]"] = {"workload": "FDN 1920x1080 (padded 1920x1088) batch=4, bf16 storage of block-internal activations, fp32 math", "value": 4e3 / ms2,
-                                   "unit": "images/s", "ms_per_step": ms2, "steps": 3, "dtype": "bf16"}
+                                   "unit": "images/s", "ms_per_step": ms2, "steps": 10, "dtype": "bf16"}
+            if not a.no_roofline:                                  # its own roofline / whole_path blocks (row g, "thin (measurement)")
+                r2, t2, p2 = roofline_of(x2, "bf16", (1080, 1920))
+                other["configs[2]"].update({"roofline": r2, "top_kernels": t2,
+                                            "whole_path": whole_path_of("bf16", x2.shape[2] * x2.shape[3], 4, 4e3 / ms2, ms2 * 1e-3, p2)})
             del x2
         finally:
             fdn_hip.set_storage_dtype("f32")
@@ -780,24 +955,14 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                        "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "fdsa_pair": bool(a.fdsa_pair), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "fdsa_pair": bool(a.fdsa_pair), "no_tail_pin": bool(a.no_tail_pin), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
                        "host_issue_ms_per_step": host_issue_ms, "cpu_affinity_rank0": affinity},
-            # B_alg = 7,256 elements per padded pixel x sizeof(elem) - 4 bytes in fp32, 2 in the bf16-storage configuration
-            "whole_path": {"hbm_algorithmic_frac": B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * (ips / world) / (PEAK_HBM_GBS * 1e9),
-                           "mfma_f32_frac": F_ALG_PER_PX * P * (ips / world) / (PEAK_F32_MFMA_TF * 1e12)},
+            "whole_path": whole_path_of(a.dtype, P, B, ips / world, dt / a.steps, prof if a.config != "lpnet" else None),
             "roofline": roof, "top_kernels": top, "cpu_baseline": cpu, "other_configs": other,
+            "parity": parity, "gpu_sensors": sensors.summary() if sensors is not None else None,
         }
         if a.config == "lpnet":
             line["whole_path"] = None                               # SURVEY 8(d)'s F_alg / B_alg are the LPNet -> FDN path's
-        elif prof is not None:
-            # SURVEY 8(d) `roofline.measured`: the bytes a step moves ACCORDING TO THE COMMITTED PMC PASSES of this shape (memory-side read
-            # requests by size + write requests, one forward of B images, recorded on the code of that profile - named in `profile` /
-            # `profile_commit`, NOT measured in this run) over THIS run's step time, against 8 TB/s
-            moved = (prof["total"]["read_GB"] + prof["total"]["write_GB"]) * 1e9
-            line["whole_path"].update({"hbm_from_committed_profile_frac": moved / (dt / a.steps) / (PEAK_HBM_GBS * 1e9),
-                                       "hbm_from_committed_profile_GB_per_step": moved / 1e9,
-                                       "hbm_from_committed_profile_over_algorithmic": moved / (B_ALG_ELEMS_PER_PX * (4.0 if a.dtype == "f32" else 2.0) * P * B),
-                                       "profile": prof["file"], "profile_commit": prof.get("commit")})
         if dt_nosg is not None:
             line["without_collectives"] = {"value": imgs / dt_nosg, "ms_per_step": dt_nosg / a.steps * 1e3,
                                            "note": "the same K steps with every rank's shard already resident (no scatter / gather)"}

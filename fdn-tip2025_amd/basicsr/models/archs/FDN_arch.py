@@ -79,7 +79,9 @@ class FDSA(nn.Module):
         self.fft = nn.Parameter(torch.ones((e, 1, 1, 8, 5)))
         self._c = _Cache()
 
-    def fused(self, x, ln=None, res=None):
+    def fused(self, x, ln=None, res=None, pin=None):
+        """pin = (FDFFN module, (gamma, beta) of the LayerNorm in front of it): the sub-block that follows; where the one-launch route can, it also
+        produces that FDFFN's project_in output and attaches it to the result (`._fdn_pin`, consumed by FDFFN.fused)."""
         e = self.expand_dim
         norms = (self.norm1, self.norm2, self.norm3)
         gam = self._c.get("g", [n.body.weight for n in norms], lambda: torch.cat([n.body.weight.detach() for n in norms]))
@@ -100,13 +102,20 @@ class FDSA(nn.Module):
             srcs = [self.to_hidden.weight] + ([ln[1], ln[2]] if ln is not None else [])
             wpk = self._c.get("pk" if ln is not None else "pk0", srcs, lambda: ops.fdsa_pack(
                 _w(self.to_hidden.weight), *((ln[1], ln[2]) if ln is not None else (None, None))))
-            if ops.FDSA_TAIL and fdn_hip.storage_dtype() == "f32" and (res is None or res.is_contiguous()):
+            if ops.FDSA_TAIL and (res is None or res.is_contiguous()):       # (both storage modes: the tile-local scratch is fp32 either way - no hand-off tensor to store)
                 # (round 6) one launch: the workgroup that produced a tile's (out1|out2|out3|v_value) planes runs the tail on them itself
-                img = self._c.get("tl", [self.project_out.weight] + [n.body.weight for n in norms] + [n.body.bias for n in norms],
-                                  lambda: ops.fdsa_tail_pack(_w(self.project_out.weight), gam, bet, x.shape[1]))
+                tsrc = [self.project_out.weight] + [n.body.weight for n in norms] + [n.body.bias for n in norms]
+                img, hd = None, 0
+                if pin is not None and ops.FDSA_TAIL_PIN and res is not None and fdn_hip.storage_dtype() == "f32":      # (bf16 mode stores h as bf16: fdn_conv1x1)
+                    pw = pin[0].project_in.weight
+                    img = self._c.get("tlp", tsrc + [pw, pin[1][0], pin[1][1]], lambda: ops.fdsa_tail_pack(
+                        _w(self.project_out.weight), gam, bet, x.shape[1], pin=ops.fold_ln(_w(pw), None, pin[1][0], pin[1][1])))
+                    hd = pw.shape[0] if img is not None else 0
+                if img is None:
+                    img = self._c.get("tl", tsrc, lambda: ops.fdsa_tail_pack(_w(self.project_out.weight), gam, bet, x.shape[1]))
                 if img is not None:
                     y = ops.fdsa_fused_tail(x, ln[0] if ln is not None else None, wpk, _w(self.to_hidden_dw.weight), _w(self.fft), img,
-                                            res=res, want_stats=res is not None)
+                                            res=res, want_stats=res is not None, Hd=hd)
                     if y is not None:
                         return y
             o = ops.fdsa_fused(x, ln[0] if ln is not None else None, wpk, _w(self.to_hidden_dw.weight), _w(self.fft),
@@ -146,7 +155,9 @@ class FDFFN(nn.Module):
 
     def fused(self, x, ln=None, res=None):
         st = ops.block_storage(x.shape[1], x.shape[2] * x.shape[3], hidden=self.project_in.weight.shape[0])      # hidden tensors: fp32, or bf16 storage (levels 1-2 in bf16 mode)
-        h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln, cache=(self._c, "pi"), out_dtype=st)
+        h = x.__dict__.pop("_fdn_pin", None) if hasattr(x, "__dict__") else None      # (round 6) the FDSA launch in front already ran project_in(LN(x)) on its registers
+        if h is None or ln is None:
+            h = ops.conv1x1(x, _w(self.project_in.weight), ln=ln, cache=(self._c, "pi"), out_dtype=st)
         y = ops.fdffn_mid(h, _w(self.space[0].weight), _w(self.space[2].weight), _w(self.ffta), _w(self.fftp))
         return ops.ffn_tail(y, _w(self.dwconv.weight), _w(self.project_out.weight), res=res, want_stats=res is not None,
                             cache=(self._c, "po"))
@@ -223,7 +234,7 @@ class TransformerBlock(nn.Module):
     def forward(self, xt):
         x, x_high, x_p, x_img = xt
         if self.att:
-            x = self.attn.fused(x, ln=(ops.stats_of(x),) + self.norm1.params(), res=x)
+            x = self.attn.fused(x, ln=(ops.stats_of(x),) + self.norm1.params(), res=x, pin=(self.ffn, self.norm2.params()))
         x = self.ffn.fused(x, ln=(ops.stats_of(x),) + self.norm2.params(), res=x)
         if self.use_light:
             if (x.shape[1] in ops.FCAFFN_IN_C or (x.shape[1] >= ops.FCAFFN_PACKED_MIN_C and fdn_hip.matrix_pipe() == "bf16")) and ops.rows_ln_ok(x):      # norm3 on load: no normalised copy of x

@@ -41,6 +41,8 @@ struct TailIo {
     float* stats_out;        // image base [2][P] or null
     int E, N, W, ty0, tx0;
     unsigned P;
+    float* h;                // PIN: image base [Hd][P] of the NEXT sub-block's project_in output (FDFFN, FDN_arch.py:456), Hd rows
+    int Hd;
 };
 
 // Level-1 form (E <= 2 SH <= 38, N <= 32): a lane owns two horizontally adjacent pixels (8-byte lanes), a wave two tile rows; fp32 MFMA.
@@ -50,8 +52,14 @@ struct TailIo {
 #else
 #define TLTR(i)
 #endif
-template <int SH>
-__device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds, unsigned long long* trc = nullptr) {
+// PIN (round 6): the FDFFN that follows every FDSA starts with project_in(LayerNorm(y)) (FDN_arch.py:456, :673) - per pixel, on exactly the values and
+// statistics this epilogue holds in registers.  It runs here as gemm_split_strip_kernel<2, FDN_PRO_LN> does (fdn_conv1x1's kernel for this shape: the
+// normalised values cut into three bf16 parts, six products per 16-deep k-step on v_mfma_f32_32x32x16_bf16, bias in the accumulator, same k slots, same
+// order: the same bits), and the C-plane read + LayerNorm + split of that launch are gone.  An MFMA result has channels (r & 3) + 8 (r >> 2) + 4 kh in
+// register r, its B operand wants channels 16 ks + 8 kh + j: four v_permlane32_swap per 16 channels move the two middle quarters across the lane halves.
+// lds_pin: [NT tiles][2 k-steps][3 parts][64 lanes] 16-byte A operands of the LayerNorm-folded weights, then NT * 32 bias floats.
+template <int SH, bool PIN = false, int NT = 3>
+__device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds, const float* lds_pin = nullptr, unsigned long long* trc = nullptr) {
     typedef fdn_f32x2 T;
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int E2 = 2 * SH, WS = 33;
@@ -142,7 +150,7 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
         outv[r] = (nrow + 4 * kh < N) ? o : T(0.f);
         sm += outv[r];
     }
-    if (io.stats_out) {
+    if (io.stats_out || PIN) {
         T sq = 0.f;
         const T mean = tl_xsum32(sm) / (float)N;
 #pragma unroll
@@ -151,14 +159,67 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
             sq += ((r & 3) + 8 * (r >> 2) + 4 * kh < N) ? dl * dl : T(0.f);
         }
         const T rstd = tl_rsqrt_eps(tl_xsum32(sq) / (float)N);
-        if (kh == 0) {
+        if (io.stats_out && kh == 0) {
             const trsrc_t rs_ = tl_rsrc(io.stats_out, 2u * P4);
             const unsigned vs = ok ? pix * 4u : 0x80000000u;
             __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(mean.x), __float_as_uint(mean.y)}, rs_, vs, 0u, 0);
             __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(rstd.x), __float_as_uint(rstd.y)}, rs_, vs, P4, 0);
         }
+        if constexpr (PIN) {
+            TLTR(6)
+            fdn_u32x4 Bf[2][2][3];                                   // [pixel of the pair][k-step][part]
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float sa = c ? rstd.y : rstd.x, sb = -(c ? mean.y : mean.x) * sa;          // gemm_split: v = fmaf(v, rstd, -mean * rstd)
+                float xn[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xn[r] = fmaf(c ? outv[r].y : outv[r].x, sa, sb);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[8];
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) {
+                        // register 8 ks + b4 holds channels 16 ks + b4 (+ 4 on the upper lanes), register 8 ks + 4 + b4 channels 16 ks + 8 + b4 (+ 4):
+                        // swap the first one's upper lanes with the second one's lower lanes
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xn[8 * ks + b4]), __float_as_uint(xn[8 * ks + 4 + b4]), false, false);
+                        v[b4] = __uint_as_float(sw[0]);
+                        v[4 + b4] = __uint_as_float(sw[1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned p1, p2, p3;
+                        fdn_split3(v[2 * j], v[2 * j + 1], p1, p2, p3);
+                        Bf[c][ks][0][j] = p1, Bf[c][ks][1][j] = p2, Bf[c][ks][2][j] = p3;
+                    }
+                }
+            }
+            const fdn_u32x4* wpin = reinterpret_cast<const fdn_u32x4*>(lds_pin) + lane;
+            const float* bpin = lds_pin + NT * 2 * 3 * 64 * 4;
+            const trsrc_t rh = tl_rsrc(io.h, (unsigned)io.Hd * P4);
+            const unsigned vh = ok ? (4u * kh * P + pix) * 4u : 0x80000000u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 ah[2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(&bpin[t * 32 + 8 * g + 4 * kh]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) ah[c][4 * g] = bv.x, ah[c][4 * g + 1] = bv.y, ah[c][4 * g + 2] = bv.z, ah[c][4 * g + 3] = bv.w;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const fdn_u32x4 a3[3] = {wpin[((t * 2 + ks) * 3 + 0) * 64], wpin[((t * 2 + ks) * 3 + 1) * 64], wpin[((t * 2 + ks) * 3 + 2) * 64]};
+                    ah[0] = fdn_mfma_split6(a3, Bf[0][ks], ah[0]);
+                    ah[1] = fdn_mfma_split6(a3, Bf[1][ks], ah[1]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)                            // rows >= Hd fall outside the descriptor
+                    __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(ah[0][r]), __float_as_uint(ah[1][r])}, rh, vh,
+                                                          (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * P4, 0);
+            }
+        }
     }
-    TLTR(6)
+    if constexpr (PIN) { TLTR(7) } else { TLTR(6) }
 }
 
 // Level-2 form (E <= 2 SH <= 76, N <= 64): one pixel per lane, a wave takes its two tile rows one after the other; project_out on the bf16 matrix pipe
@@ -346,6 +407,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
     }
     TLTR(6)
 }
+__host__ __device__ constexpr int tl_pin_floats(int NT) { return NT * 2 * 3 * 64 * 4 + 256; }        // A operands + one KB of bias
 __host__ __device__ constexpr int tl_image_floats_px1(int SH, int MT) { return 512 + 3 * ((SH + 7) / 8) * MT * 3 * 64 * 4; }
 
 }  // namespace

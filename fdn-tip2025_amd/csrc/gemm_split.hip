@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SArgs a) {
             }
         } else {
             const int k0 = c * KC + 16 * hh;
-            const bool second = PRO == FDN_PRO_NONE && k0 >= K0;              // wave-uniform
+            const bool second = PRO == FDN_PRO_NONE && d.kseg[1] > 0 && k0 >= K0;      // wave-uniform; one input: k >= K stays on rx, outside its descriptor (reads 0)
             const rsrc_t rxc = second ? rx1 : rx;
             const int kb = second ? k0 - K0 : k0;
 #pragma unroll

@@ -600,6 +600,8 @@ struct FusedArgs {
     float* y;
     float* stats_out;
     int N;
+    float* h;            // TAIL 3: the following FDFFN's project_in output [B][Hd][H][W]
+    int Hd;
 };
 
 #ifndef FDN_FUSED_WGS
@@ -1005,12 +1007,14 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         // (measured: an explicit s_waitcnt vmcnt(0) here - what a scratch reload implies - costs 1.8 % at C = 32, 1 % at C = 64: profiles/r05_l_fused64_ab.txt)
         // (the next chunk's row phase rewrites S behind the barrier at the top of the loop, i.e. after every thread has finished these reads)
     }
-    if constexpr (TAIL == 1) {
+    if constexpr (TAIL == 1 || TAIL == 3) {
         // ---- the tail, on this workgroup's own planes (fdsa_tail.hpp).  `hid` is dead behind the last chunk's third barrier: the operand image
         // (gamma | beta | transposed project_out) goes global -> LDS directly, no registers; its arrival, and every store of the planes, is what
         // vmcnt(0) waits for; behind the barrier the planes are in L2 (or beyond), visible to the sc1 loads of every wave of this workgroup
         constexpr int SH = 19;
-        constexpr int NBLK = tl_image_floats(SH, 1) / 256;
+        constexpr bool PIN = TAIL == 3;          // + the next sub-block's project_in (operands behind the tail's own image)
+        constexpr int NBLK0 = tl_image_floats(SH, 1) / 256;
+        constexpr int NBLK = NBLK0 + (PIN ? tl_pin_floats(3) / 256 : 0);
 #ifdef FDN_FUSED_TRACE
         if (trc) trc[40] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1035,10 +1039,12 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         io.y = a.y + (long)b * a.N * P;
         io.stats_out = a.stats_out ? a.stats_out + (long)b * 2 * P : nullptr;
         io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
+        io.h = PIN ? a.h + (long)b * a.Hd * P : nullptr;
+        io.Hd = a.Hd;
 #ifdef FDN_FUSED_TRACE
-        fdsa_tail_px2<SH>(io, hid, trc);
+        fdsa_tail_px2<SH, PIN>(io, hid, hid + NBLK0 * 256, trc);
 #else
-        fdsa_tail_px2<SH>(io, hid);
+        fdsa_tail_px2<SH, PIN>(io, hid, hid + NBLK0 * 256);
 #endif
     }
     if constexpr (TAIL == 2) {
@@ -1074,6 +1080,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         io.y = a.y + (long)b * a.N * P;
         io.stats_out = a.stats_out ? a.stats_out + (long)b * 2 * P : nullptr;
         io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
+        io.h = nullptr; io.Hd = 0;
 #ifdef FDN_FUSED_TRACE
         fdsa_tail_px1<SH, MT>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw, trc);
 #else
@@ -1260,6 +1267,34 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
     return fdn_launch_status();
 }
 
+// project_in's operands behind the level-1 image (fdsa_tail_px2<.., PIN>): [NT][2 k-steps][3 parts][64 lanes] 16-byte A operands of the LayerNorm-folded
+// weights wf [Hd][C] - lane (n, kh) holds the part-th bf16 part of wf[32 t + n][16 ks + 8 kh + 0..7] - then NT * 32 folded bias values, padded to one KB
+static __global__ void fdsa_tail_pack_pin_kernel(const float* __restrict__ wf, const float* __restrict__ bf, float* __restrict__ img, int C, int Hd, int NT) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nop = NT * 2 * 3 * 64;
+    if (i < nop) {
+        const int l = i & 63, part = (i >> 6) % 3, ks = (i / 192) & 1, t = i / 384;
+        const int n = t * 32 + (l & 31), kh = l >> 5;
+        fdn_u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned hl[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 16 * ks + 8 * kh + 2 * d + h;
+                float x = (n < Hd && k < C) ? wf[(long)n * C + k] : 0.f;
+                for (int pp = 0; pp < part; ++pp) x -= fdn_trunc_bf16(x);
+                hl[h] = __float_as_uint(x) >> 16;
+            }
+            o[d] = hl[0] | (hl[1] << 16);
+        }
+        reinterpret_cast<fdn_u32x4*>(img)[i] = o;
+    } else if (i < nop + 256) {
+        const int j = i - nop;
+        img[nop * 4 + j] = (bf && j < Hd && j < NT * 32) ? bf[j] : 0.f;
+    }
+}
+
 // the level-2 image: [gamma 3 E2 | pad][beta 3 E2 | pad][Wp [3][NQ][MT][part][64] A operands of v_mfma_f32_32x32x16_bf16]: lane l = (n = mt 32 + (l & 31), k2 = l >> 5)
 // holds channels e = 2 (8 q + 2 d + h) + k2, d = 0..3, h = 0..1, cut into the part-th bf16 part (fdsa_out_vec_kernel's in-kernel packing, done once here)
 static __global__ void fdsa_tail_pack_px1_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ img,
@@ -1298,32 +1333,38 @@ static int fdsa_tail_form(int C, int E, int N, int* sh, int* mt) {      // 0 = n
     if ((C == 48 || C == 64) && E > 38 && E <= 76 && N > 32 && N <= 64) { *sh = 38; *mt = 2; return 2; }
     return 0;
 }
-extern "C" long fdn_fdsa_tail_pack_floats(int C, int E, int N) {
+static bool fdsa_tail_pin_ok(int form, int C, int Hd) { return form == 1 && Hd > 0 && Hd <= 96 && 2 * Hd >= 5 * C; }      // fdn_conv1x1's strip<2> shapes
+extern "C" long fdn_fdsa_tail_pack_floats(int C, int E, int N, int Hd) {
     int sh, mt;
     const int form = fdsa_tail_form(C, E, N, &sh, &mt);
-    return form == 1 ? tl_image_floats(sh, mt) : form == 2 ? tl_image_floats_px1(sh, mt) : 0;
+    if (Hd > 0 && !fdsa_tail_pin_ok(form, C, Hd)) return 0;
+    return form == 1 ? tl_image_floats(sh, mt) + (Hd > 0 ? tl_pin_floats(3) : 0) : form == 2 ? tl_image_floats_px1(sh, mt) : 0;
 }
 extern "C" long fdn_fdsa_scratch_floats(int B, int E, int H, int W) {
     if (B <= 0 || E <= 0 || H <= 0 || W <= 0 || H % 8) return 0;
     return (long)B * (H / FT_H) * cdiv(W, FT_W) * 4 * E * 256;
 }
-extern "C" int fdn_fdsa_tail_pack(const float* w, const float* gamma3, const float* beta3, float* img, int C, int E, int N, fdn_stream_t stream) {
-    FDN_CHECK_ARG(w && gamma3 && beta3 && img && E > 0 && N > 0);
+extern "C" int fdn_fdsa_tail_pack(const float* w, const float* gamma3, const float* beta3, const float* pin_w, const float* pin_b, float* img, int C,
+                                  int E, int N, int Hd, fdn_stream_t stream) {
+    FDN_CHECK_ARG(w && gamma3 && beta3 && img && E > 0 && N > 0 && (Hd == 0) == (pin_w == nullptr));
     int sh, mt;
     const int form = fdsa_tail_form(C, E, N, &sh, &mt);
-    if (!form) return FDN_ERR_UNSUPPORTED;
+    if (!form || (Hd > 0 && !fdsa_tail_pin_ok(form, C, Hd))) return FDN_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     if (form == 2) {
         const int nthreads = 512 + (tl_image_floats_px1(sh, mt) - 512) / 4;     // 512 header floats + one thread per 16-byte operand
-        hipLaunchKernelGGL(fdsa_tail_pack_px1_kernel, dim3(cdiv(nthreads, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma3, beta3, img, E, N, sh, mt);
+        hipLaunchKernelGGL(fdsa_tail_pack_px1_kernel, dim3(cdiv(nthreads, 256)), dim3(256), 0, s, w, gamma3, beta3, img, E, N, sh, mt);
         return fdn_launch_status();
     }
     const int total = tl_image_floats(sh, mt);
-    hipLaunchKernelGGL(fdsa_tail_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, gamma3, beta3, img, E, N, sh, mt, total);
+    hipLaunchKernelGGL(fdsa_tail_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, gamma3, beta3, img, E, N, sh, mt, total);
+    if (Hd > 0)
+        hipLaunchKernelGGL(fdsa_tail_pack_pin_kernel, dim3(cdiv(3 * 2 * 3 * 64 + 256, 256)), dim3(256), 0, s, pin_w, pin_b, img + total, C, Hd, 3);
     return fdn_launch_status();
 }
 extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
-                                   const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, int B, int C,
-                                   int E, int H, int W, fdn_stream_t stream) {
+                                   const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, float* h_out, int B,
+                                   int C, int E, int H, int W, int Hd, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && wpk && dw_w && fft_w && tail_img && out && scratch && B > 0 && E > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0);
     FDN_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(stats_out) |
@@ -1334,6 +1375,10 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     int sh, mt;
     const int form = fdsa_tail_form(C, E, C, &sh, &mt);
     if (!form || (form == 1 && W % 2)) return FDN_ERR_UNSUPPORTED;
+    if (form == 2 && !fdn_matrix_pipe_wide()) return FDN_ERR_UNSUPPORTED;       // fdn_set_matrix_pipe(2): the level-2 tail keeps its fp32-MFMA form (fdn_fdsa_out)
+    FDN_CHECK_ARG((Hd == 0) == (h_out == nullptr) && (reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
+    if (Hd > 0 && !fdsa_tail_pin_ok(form, C, Hd)) return FDN_ERR_UNSUPPORTED;
+    FDN_CHECK_ARG(4ull * (Hd + 40) * H * W < 0x80000000ull);
     FusedArgs a;
     a.x = x; a.xbs = xbs; a.stats = stats; a.wpk = wpk; a.dww = dw_w; a.fftw = fft_w; a.out = scratch;
     a.E = E; a.H = H; a.W = W;
@@ -1341,6 +1386,7 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     a.tiles_per_img = a.tiles_x * (H / FT_H);
     a.nchunks = (E + FEG - 1) / FEG;
     a.tw = tail_img; a.res = res; a.y = out; a.stats_out = stats_out; a.N = C;
+    a.h = h_out; a.Hd = Hd;
     const long total = (long)B * a.tiles_per_img;
     FDN_CHECK_ARG(total < 0x7fffffffL);
     const dim3 grid((unsigned)total), block(256);
@@ -1351,10 +1397,22 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
         else hipLaunchKernelGGL((fdsa_fused_kernel<CC, false, false, TT>), grid, block, 0, s, a);           \
         break;
     switch (C) {
-        FDN_FUSED_TAIL_CASE(24, 1)
-        FDN_FUSED_TAIL_CASE(32, 1)
         FDN_FUSED_TAIL_CASE(48, 2)
         FDN_FUSED_TAIL_CASE(64, 2)
+        case 24:
+        case 32:
+            if (Hd > 0) {
+                switch (C) {
+                    FDN_FUSED_TAIL_CASE(24, 3)
+                    FDN_FUSED_TAIL_CASE(32, 3)
+                }
+            } else {
+                switch (C) {
+                    FDN_FUSED_TAIL_CASE(24, 1)
+                    FDN_FUSED_TAIL_CASE(32, 1)
+                }
+            }
+            break;
         default: return FDN_ERR_UNSUPPORTED;
     }
 #undef FDN_FUSED_TAIL_CASE

@@ -11,6 +11,7 @@ from . import (ACT_NONE, EPI_MULADD, EPI_NONE, EPI_RES, PRO_LN, PRO_LN3_GATE, PR
                Conv1x1Desc, FdnHipError, check, lib, storage_dtype, stream)
 
 BF16 = torch.bfloat16
+ERR_UNSUPPORTED = 4          # FDN_ERR_UNSUPPORTED of include/fdn_hip.h: the library has no form for this shape / mode (the caller takes another route)
 
 
 def _planes(t, what, bf16_ok=False):
@@ -182,12 +183,17 @@ def conv1x1(xs, w, bias=None, *, out=None, act=ACT_NONE, ln=None, ln3_gate=None,
         d.mul, d.mbs = _planes(muladd[0], "mul")
         d.add, mbs2 = _planes(muladd[1], "add")
         assert mbs2 == d.mbs
+    if d.pro in (PRO_LN3_GATE, PRO_LN_MULADD) and not d.stats and not d.wpk:
+        # only the K-streaming split-bf16 kernel (packed operands: the predicate above, bf16 matrix pipe) takes its tile's LayerNorm statistics itself;
+        # every other shape / mode gets the fdn_chan_stats launch here instead of a refused call first
+        auto = chan_stats(xs[0], groups=3) if ln3_gate is not None else chan_stats(xs[0])
+        d.stats = _flat(auto, "stats")
     stats = None
     if want_stats and N <= 160:
         stats = torch.empty((B, 1, 2, P), device=out.device, dtype=torch.float32)
         d.stats_out = _flat(stats, "stats_out")
     rc = lib().fdn_conv1x1(ctypes.byref(d), stream())
-    if rc == 4 and d.pro in (PRO_LN3_GATE, PRO_LN_MULADD) and not d.stats:      # FDN_ERR_UNSUPPORTED: no kernel of this shape takes the statistics itself
+    if rc == ERR_UNSUPPORTED and d.pro in (PRO_LN3_GATE, PRO_LN_MULADD) and not d.stats:      # safety net: no kernel of this shape takes the statistics itself
         x0 = xs[0]
         auto = chan_stats(x0, groups=3) if ln3_gate is not None else chan_stats(x0)
         d.stats = _flat(auto, "stats")
@@ -265,22 +271,26 @@ FDSA_TAIL = True            # (round 6) levels 1-2: fdn_fdsa_fused_tail - the pr
 _fdsa_scratch = {}          # (device, floats) -> scratch tensor of fdn_fdsa_fused_tail: one per device and size, shared by every block (one stream per GPU)
 
 
-def fdsa_tail_pack(w_out, gamma3, beta3, C):
-    """project_out [N, 3E(,1,1)] + norm1..3 -> the LDS operand image of fdn_fdsa_fused_tail's in-kernel tail; None = no form for this width."""
+def fdsa_tail_pack(w_out, gamma3, beta3, C, pin=None):
+    """project_out [N, 3E(,1,1)] + norm1..3 -> the LDS operand image of fdn_fdsa_fused_tail's in-kernel tail; None = no form for this width.
+    pin = (wf [Hd, C], bf [Hd]): the LayerNorm-folded project_in of the FDFFN behind the FDSA (fold_ln), run by the same tail (level 1)."""
     N = w_out.shape[0]
     E = w_out.numel() // N // 3
-    n = lib().fdn_fdsa_tail_pack_floats(C, E, N)
+    Hd = pin[0].shape[0] if pin is not None else 0
+    n = lib().fdn_fdsa_tail_pack_floats(C, E, N, Hd)
     if n <= 0:
         return None
     img = torch.empty(n, device=w_out.device, dtype=torch.float32)
-    check(lib().fdn_fdsa_tail_pack(_flat(w_out.reshape(N, 3 * E), "w_out"), _flat(gamma3, "gamma3"), _flat(beta3, "beta3"), _flat(img, "img"),
-                                   C, E, N, stream()), "fdn_fdsa_tail_pack")
+    check(lib().fdn_fdsa_tail_pack(_flat(w_out.reshape(N, 3 * E), "w_out"), _flat(gamma3, "gamma3"), _flat(beta3, "beta3"),
+                                   _flat(pin[0].reshape(Hd, C), "pin_w") if pin is not None else None, _flat(pin[1], "pin_b") if pin is not None else None,
+                                   _flat(img, "img"), C, E, N, Hd, stream()), "fdn_fdsa_tail_pack")
     return img
 
 
-def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=False):
+def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=False, Hd=0):
     """x [B,C,H,W] -> res + project_out(norm1..3(FDSA core(LN(x))) * v_value) in ONE launch (fdn_fdsa_fused_tail), bit-identical to
-    fdsa_fused + fdsa_out.  Returns None when the library has no form for the shape."""
+    fdsa_fused + fdsa_out.  Hd > 0 (tail_img packed with `pin`): also h = project_in(LN(out)) [B,Hd,H,W] of the FDFFN that follows, attached to
+    the result as `._fdn_pin`.  Returns None when the library has no form for the shape."""
     B, C, H, W = x.shape
     E = dw_w.shape[0] // 4
     ptr, xbs = _planes(x, "x")
@@ -291,17 +301,21 @@ def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=F
         scr = _fdsa_scratch[key] = torch.empty(n, device=x.device, dtype=torch.float32)
     out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
     st = torch.empty((B, 1, 2, H * W), device=x.device, dtype=torch.float32) if want_stats else None
+    h = torch.empty((B, Hd, H, W), device=x.device, dtype=torch.float32) if Hd else None
     rc = lib().fdn_fdsa_fused_tail(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), _flat(wpk, "wpk"), _flat(dw_w, "dw_w"), _flat(fft_w, "fft_w"),
                                    _flat(tail_img, "tail_img"), _flat(res, "res"), _flat(out, "out"), _flat(st, "stats_out"), _flat(scr, "scratch"),
-                                   B, C, E, H, W, stream())
-    if rc == 4:
+                                   _flat(h, "h_out"), B, C, E, H, W, Hd, stream())
+    if rc == ERR_UNSUPPORTED:
         return None
     check(rc, "fdn_fdsa_fused_tail")
     if want_stats:
         out._fdn_stats = st
+    if Hd:
+        out._fdn_pin = h
     return out
 
 
+FDSA_TAIL_PIN = True        # (round 6) level 1: that launch also runs the following FDFFN's project_in (bit-identical to fdn_conv1x1's kernel for the shape)
 FDSA_FULL = False           # True: the whole FDSA sub-block in one launch (fdn_fdsa_full) for C <= FDSA_FULL_MAX_C; False: fdn_fdsa_fused + fdn_fdsa_out
 FDSA_FULL_MAX_C = 32        # measured (tools/ab_fdsa_full.py, B = 8 720p shapes): one launch 3.52 against 3.77 ms at C = 32 and 2.89 against 2.93 at
                             # C = 24 (8 x 16 tiles, 8-channel chunks); at C = 48 / 64 (8 x 8 tiles, 16-channel chunks) it loses, 2.63 against 2.25 ms
@@ -332,7 +346,7 @@ def fdsa_full(x, stats, wpk, dw_w, fft_w, res=None, want_stats=False):
     ptr, xbs = _planes(x, "x")
     rc = lib().fdn_fdsa_full(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), ctypes.c_void_p(wpk.data_ptr()), _flat(dw_w, "dw_w"),
                              _flat(fft_w, "fft_w"), _flat(res, "res"), _flat(out, "out"), _flat(st, "stats_out"), B, C, E, H, W, stream())
-    if rc == 4:                 # FDN_ERR_UNSUPPORTED
+    if rc == ERR_UNSUPPORTED:
         return None
     check(rc, "fdn_fdsa_full")
     if want_stats:
@@ -350,7 +364,7 @@ def fdsa_out(o, w, gamma3, beta3, res=None, want_stats=False):
     stats = torch.empty((B, 1, 2, P), device=o.device, dtype=torch.float32) if want_stats else None
     rc = lib().fdn_fdsa_out(_flat(o, "o", True), _flat(w, "w"), _flat(gamma3, "gamma3"), _flat(beta3, "beta3"), _flat(res, "res"),
                             _flat(out, "out"), _flat(stats, "stats_out"), B, E, N, P, int(o.dtype == BF16), stream())
-    if rc == 4 and o.dtype != BF16:          # FDN_ERR_UNSUPPORTED: the caller takes the statistics + GEMM route (fp32 only)
+    if rc == ERR_UNSUPPORTED and o.dtype != BF16:          # the caller takes the statistics + GEMM route (fp32 only)
         return None
     check(rc, "fdn_fdsa_out")
     if want_stats:

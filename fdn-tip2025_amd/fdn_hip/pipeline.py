@@ -44,14 +44,17 @@ def _get_streams(device, n):
     return _streams[key]
 
 
-def forward_streams(net, lpnet, x, n_streams=1):
+def forward_streams(net, lpnet, x, n_streams=1, keep=None):
     """result = FDN(x, ratio_i=LPNet(x))[0]; n_streams > 1 splits the batch over HIP streams (see the module note: not
-    bit-stable on MI355X / ROCm 7.2, experiments only)."""
+    bit-stable on MI355X / ROCm 7.2, experiments only).  keep: a dict that receives the LPNet output as keep["ratio"] (one stream only)."""
     _check_streams(n_streams)
     B = x.shape[0]
     if n_streams <= 1 or B < n_streams:
         with torch.no_grad():
-            return net(x, ratio_i=lpnet(x), device=x.device)[0]
+            ratio = lpnet(x)
+            if keep is not None:
+                keep["ratio"] = ratio
+            return net(x, ratio_i=ratio, device=x.device)[0]
     cur = torch.cuda.current_stream(x.device)
     streams = _get_streams(x.device, n_streams)
     bounds = [round(i * B / n_streams) for i in range(n_streams + 1)]
@@ -75,7 +78,7 @@ def weights_signature(*modules):
     change of ops.FDSA_FULL the key differs and the holder captures again."""
     from . import matrix_pipe_mode, ops
     ps = [p for m in modules for p in list(m.parameters()) + list(m.buffers())]
-    return (storage_dtype(), matrix_pipe_mode(), bool(ops.FDSA_FULL), int(ops.FDSA_FULL_MAX_C), bool(ops.FDSA_TAIL), str(ops.FFN_TAIL_MODE), bool(ops.SPECTRAL_MLP_FUSED), bool(ops.GEMM_OWN_STATS), bool(ops.UPCONV_GATHER), bool(ops.AFF_MULTIRES),
+    return (storage_dtype(), matrix_pipe_mode(), bool(ops.FDSA_FULL), int(ops.FDSA_FULL_MAX_C), bool(ops.FDSA_TAIL), bool(ops.FDSA_TAIL_PIN), str(ops.FFN_TAIL_MODE), bool(ops.SPECTRAL_MLP_FUSED), bool(ops.GEMM_OWN_STATS), bool(ops.UPCONV_GATHER), bool(ops.AFF_MULTIRES),
             len(ps), sum(p._version for p in ps), sum(p.data_ptr() & 0xFFFFFFFF for p in ps))
 
 
@@ -181,11 +184,17 @@ class GraphedStep:
                 forward_streams(self.net, self.lpnet, self._x, self.n)
             torch.cuda.synchronize(x.device)
             self._g = torch.cuda.CUDAGraph()
+            self._keep = {}
             with torch.cuda.graph(self._g, capture_error_mode=CAPTURE_MODE):
-                self._out = forward_streams(self.net, self.lpnet, self._x, self.n)
+                self._out = forward_streams(self.net, self.lpnet, self._x, self.n, keep=self._keep)
         self._x.copy_(x)
         self._g.replay()
         return self._out
+
+    @property
+    def ratio(self):
+        """LPNet's output of the last replay (a tensor of the graph's pool, overwritten by the next call); None with several streams."""
+        return self._keep.get("ratio") if self._g is not None else None
 
 
 GRAPH_BELOW_PIXELS = 1 << 20          # B*H*W under which a forward is launch-bound (256 x 256: 23 ms eager vs ~6 ms of kernels)

@@ -76,20 +76,17 @@ def gather_uneven(dist, out, total, dst=0):
 def sharded_run(dist, forward, total, sample_like, x_all=None, root=0):
     """One pass over a global batch of ANY size: scatter_uneven -> forward on the local items -> gather_uneven, strictly serial like
     sharded_step (blocking collectives on the compute stream's timeline).  `forward` must accept a batch of this rank's item count (it is not
-    called on a rank that received no item; such a rank contributes an empty block shaped by `out_like` = forward's output for one item, which the
-    root learns from its own shard - the root always holds at least one item when total >= 1)."""
+    called on a rank that received no item; such a rank contributes an empty block with the trailing shape and dtype of forward's output, which
+    rank 0 - the one rank that always holds an item when total >= 1 - broadcasts)."""
     xin = scatter_uneven(dist, total, sample_like, x_all, src=root)
-    if xin.shape[0]:
-        out = forward(xin)
-        tail = torch.tensor(list(out.shape[1:]), dtype=torch.int64)
-    else:
-        out, tail = None, None
-    # ranks without an item need the output's trailing shape to take part in the gather: the root (which has one) tells them
+    out = forward(xin) if xin.shape[0] else None
+    # ranks without an item need the output's trailing shape AND dtype to take part in the gather.  Rank 0 tells them: shard_bounds gives the
+    # extra items to the LOWEST ranks, so rank 0 owns item 0 whenever total >= 1 - the root need not own any (root != 0 with total < world)
     if total < dist.get_world_size():
-        shape = [tail.tolist() if dist.get_rank() == root else None]
-        dist.broadcast_object_list(shape, src=root)
+        desc = [(list(out.shape[1:]), out.dtype) if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(desc, src=0)
         if out is None:
-            out = sample_like.new_empty((0,) + tuple(shape[0]))
+            out = torch.empty((0,) + tuple(desc[0][0]), dtype=desc[0][1], device=sample_like.device)
     return gather_uneven(dist, out, total, dst=root)
 
 

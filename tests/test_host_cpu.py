@@ -244,6 +244,30 @@ def test_reference_driver_imports_through_the_shadow(tmp_path):
     assert r.returncode == 0 and "shadow ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_reference_model_registry_is_reached_on_demand(tmp_path):
+    """`from basicsr.models import create_model` (the reference's test.py / train.py) - the shadow package runs the checkout's
+    basicsr/models/__init__.py the first time one of its names is asked for, and says so when that fails or when no checkout follows."""
+    import subprocess
+    import sys
+    ck = tmp_path / "checkout"
+    (ck / "basicsr" / "models").mkdir(parents=True)
+    (ck / "basicsr" / "models" / "__init__.py").write_text("def create_model(opt):\n    return ('model of the checkout', opt)\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([entry.PKG, str(ck)]))
+    code = ("from basicsr.models import create_model\nassert create_model(3) == ('model of the checkout', 3)\n"
+            "import basicsr.models as m\n"
+            "try:\n    m.no_such_name\nexcept AttributeError as e:\n    assert 'drop-in' in str(e)\nelse:\n    raise SystemExit('no error')\nprint('registry ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "registry ok" in r.stdout, r.stderr[-2000:]
+    (ck / "basicsr" / "models" / "__init__.py").write_text("import a_module_the_training_stack_needs\n")
+    code = ("try:\n    from basicsr.models import create_model\nexcept ImportError as e:\n"
+            "    assert 'on demand' in str(e) and 'a_module_the_training_stack_needs' in str(e), str(e)\n    print('clear error')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "clear error" in r.stdout, r.stderr[-2000:]
+    code = ("import basicsr.models as m\ntry:\n    m.create_model\nexcept AttributeError as e:\n    assert 'no reference checkout' in str(e), str(e)\n    print('clear error')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=entry.PKG), capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "clear error" in r.stdout, r.stderr[-2000:]
+
+
 def test_bench_describes_calls_by_name():
     """bench.py's roofline figures come from the ARGUMENTS of the C-ABI calls it wraps.  They are read by NAME (fdn_hip/_abi.py ARG_NAMES,
     generated from the header), so an inserted or reordered parameter of a later ABI version cannot silently shift a shape: every parser gets
@@ -290,3 +314,31 @@ def test_bench_describes_calls_by_name():
             assert key2 != key, (name, key, key2)
     with pytest.raises(TypeError):
         bench.describe_call("fdn_fdsa_fused", [None] * 3)       # a call that does not match the declared parameter count is refused
+
+
+def test_graph_key_covers_every_routing_switch():
+    """A captured HIP graph replays the kernels of its capture: every process-wide switch that decides WHICH kernels a forward launches must be part of
+    pipeline.weights_signature, or a holder would replay a stale route (ops.FFN_TAIL_MODE was missing).  Checked on CPU modules."""
+    import torch
+    from fdn_hip import ops, pipeline
+    m = torch.nn.Linear(3, 3)
+    base = pipeline.weights_signature(m)
+    flips = {"FDSA_FULL": True, "FDSA_FULL_MAX_C": 64, "FDSA_TAIL": False, "FDSA_TAIL_PIN": False, "FFN_TAIL_MODE": "split", "SPECTRAL_MLP_FUSED": False,
+             "GEMM_OWN_STATS": False, "UPCONV_GATHER": False, "AFF_MULTIRES": False}
+    # every module-level switch of ops.py whose initial value is a bool or None (the routing switches; thresholds and width tables are constants)
+    import re
+    src = open(ops.__file__).read()
+    switches = set(re.findall(r"^([A-Z][A-Z0-9_]*) = (?:True|False|None)\b", src, flags=re.M))
+    assert switches <= set(flips), f"routing switches missing from this test (and maybe from the graph key): {sorted(switches - set(flips))}"
+    for name, val in flips.items():
+        old = getattr(ops, name)
+        assert old != val, name
+        setattr(ops, name, val)
+        try:
+            assert pipeline.weights_signature(m) != base, f"ops.{name} is not part of the graph key"
+        finally:
+            setattr(ops, name, old)
+    assert pipeline.weights_signature(m) == base
+    with torch.no_grad():
+        m.weight.add_(1.0)                      # an in-place weight update is seen too
+    assert pipeline.weights_signature(m) != base

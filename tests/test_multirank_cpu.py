@@ -195,7 +195,7 @@ def test_graphed_forward_does_not_travel_with_copies():
     assert st.net is None and len(st._graphs) == 0
 
 
-def _uneven_worker(rank, world, port, total, q):
+def _uneven_worker(rank, world, port, total, q, root=0):
     sys.path.insert(0, os.path.join(ROOT, "fdn-tip2025_amd"))
     from fdn_hip import sharding
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -206,15 +206,32 @@ def _uneven_worker(rank, world, port, total, q):
 
     def forward(x):                                          # per-sample independent stand-in with a different output shape
         seen.append(x.shape[0])
-        return (x * 2.0 + x.flip(-1))[:, :, ::2].contiguous()
-    y = sharding.sharded_run(dist, forward, total, torch.empty(1, 3, 8, 12), x_all if rank == 0 else None)
+        y_ = (x * 2.0 + x.flip(-1))[:, :, ::2].contiguous()
+        return y_.double() if root else y_                   # (root != 0: the forward also changes the dtype)
+    y = sharding.sharded_run(dist, forward, total, torch.empty(1, 3, 8, 12), x_all if rank == root else None, root=root)
     b = sharding.shard_bounds(total, world)
     ok_count = seen == ([b[rank + 1] - b[rank]] if b[rank + 1] > b[rank] else [])
     flags = [None] * world
     dist.all_gather_object(flags, ok_count)
-    if rank == 0:
+    if rank == root:
         q.put((torch.equal(y, forward(x_all)), all(flags), tuple(y.shape)))
     dist.destroy_process_group()
+
+
+def test_uneven_batch_with_a_root_that_owns_no_item():
+    """root = 1 with a global batch of ONE item - the root holds the batch but owns no item (shard_bounds gives the extra items to the
+    lowest ranks), and the forward changes the dtype: rank 0 (which always owns item 0) broadcasts the output's trailing shape and dtype, the root
+    contributes an empty block of that dtype, nobody hangs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33900 + os.getpid() % 2000
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, 1, q, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, counts_ok, shape = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+    assert same and counts_ok and shape == (1, 3, 4, 12), (same, counts_ok, shape)
 
 
 def test_global_batch_not_a_multiple_of_the_world_size():

@@ -32,23 +32,37 @@ def case(B, C, H, W, time_it=True, edge=False):
     wp = r(C, 3 * E) / (3 * E) ** .5
     g3, b3 = r(3 * E), r(3 * E)
     wpk = ops.fdsa_pack(wh, gm, bt)
+    Hd = int(C * 2.7)
+    wi, g2, b2 = r(Hd, C) / C ** .5, r(C), r(C)           # the FDFFN behind the FDSA: project_in with its LayerNorm
+    cache = ops.WeightCache()
     img = ops.fdsa_tail_pack(wp, g3, b3, C)
     if img is None:
         print(f"C={C}: no in-kernel tail"); return
+    imgp = ops.fdsa_tail_pack(wp, g3, b3, C, pin=ops.fold_ln(wi, None, g2, b2))
 
-    def pair():
+    def pair(with_pin=False):
         o = ops.fdsa_fused(x, stats, wpk, dw, fw)
-        return ops.fdsa_out(o, wp, g3, b3, res=x, want_stats=True)
+        y = ops.fdsa_out(o, wp, g3, b3, res=x, want_stats=True)
+        if with_pin:
+            y._fdn_pin = ops.conv1x1(y, wi, ln=(y._fdn_stats, g2, b2), cache=(cache, "pi"))
+        return y
 
-    def one():
+    def one(with_pin=False):
+        if with_pin:
+            return ops.fdsa_fused_tail(x, stats, wpk, dw, fw, imgp, res=x, want_stats=True, Hd=Hd)
         return ops.fdsa_fused_tail(x, stats, wpk, dw, fw, img, res=x, want_stats=True)
 
-    ya, yb = pair(), one()
+    ya, yb = pair(imgp is not None), one()
     torch.cuda.synchronize()
     same = torch.equal(ya, yb) and torch.equal(ya._fdn_stats, yb._fdn_stats)
     d = (ya - yb).abs().max().item()
     print(f"B={B} C={C} {H}x{W}{' edge' if edge else ''}: bit-identical {same} (max |diff| {d:.3e}, stats {(ya._fdn_stats - yb._fdn_stats).abs().max().item():.3e}, "
           f"nan {int(torch.isnan(yb).sum())})", flush=True)
+    if imgp is not None:
+        yc = one(True)
+        torch.cuda.synchronize()
+        samep = torch.equal(ya, yc) and torch.equal(ya._fdn_stats, yc._fdn_stats) and torch.equal(ya._fdn_pin, yc._fdn_pin)
+        print(f"   with project_in {C}->{Hd}: bit-identical {samep} (h max |diff| {(ya._fdn_pin - yc._fdn_pin).abs().max().item():.3e}, nan {int(torch.isnan(yc._fdn_pin).sum())})", flush=True)
     if not time_it:
         return
 
@@ -62,10 +76,15 @@ def case(B, C, H, W, time_it=True, edge=False):
 
     fused_only = lambda: ops.fdsa_fused(x, stats, wpk, dw, fw)
     res = {"pair": [], "fused_only": [], "one": []}
-    for f in (pair, fused_only, one):
+    fs = [("pair", pair), ("fused_only", fused_only), ("one", one)]
+    if imgp is not None:
+        res.update({"pair+project_in": [], "one+project_in": []})
+        fs += [("pair+project_in", lambda: pair(True)), ("one+project_in", lambda: one(True))]
+    for _, f in fs:
         timeit(f, 2)
     for _ in range(reps):
-        res["pair"].append(timeit(pair)); res["fused_only"].append(timeit(fused_only)); res["one"].append(timeit(one))
+        for k, f in fs:
+            res[k].append(timeit(f))
     print("   " + "   ".join(f"{k}: {statistics.median(v):.3f} ms (min {min(v):.3f})" for k, v in res.items()), flush=True)
 
 

@@ -15,6 +15,9 @@ import fdn_hip
 fdn_hip._LIB_PATH = os.path.abspath(sys.argv[1])
 from fdn_hip import ops
 TAIL = "--tail" in sys.argv          # (round 6) fdn_fdsa_fused_tail: the tail's stamps 40..46 (loop exit, stores drained, barrier, group 0 normalised = its data arrived,
+PIN = "--pin" in sys.argv            # ... and with the following FDFFN's project_in in the same launch (stamp 47: its last store issued)
+if PIN:
+    sys.argv.remove("--pin")
 if TAIL:                             #  group 0's MFMAs issued, group 2's MFMAs issued, epilogue stores issued); E <= 40 only (five chunks)
     sys.argv.remove("--tail")
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 32
@@ -41,8 +44,11 @@ for it in range(3):
     if TAIL:
         gt = torch.Generator().manual_seed(2)
         wo = (torch.randn(C, 3 * E, generator=gt) / (3 * E) ** .5).to(dev)
-        img = ops.fdsa_tail_pack(wo, torch.ones(3 * E, device=dev), torch.zeros(3 * E, device=dev), C)
-        out = ops.fdsa_fused_tail(x, stats, wpk, dw.reshape(4 * E, 1, 3, 3), fw, img, res=x, want_stats=True)
+        Hd = int(2.7 * C)
+        wi = (torch.randn(Hd, C, generator=gt) / C ** .5).to(dev)
+        img = ops.fdsa_tail_pack(wo, torch.ones(3 * E, device=dev), torch.zeros(3 * E, device=dev), C,
+                                 pin=ops.fold_ln(wi, None, torch.ones(C, device=dev), torch.zeros(C, device=dev)) if PIN else None)
+        out = ops.fdsa_fused_tail(x, stats, wpk, dw.reshape(4 * E, 1, 3, 3), fw, img, res=x, want_stats=True, Hd=Hd if PIN else 0)
     else:
         out = ops.fdsa_fused(x, stats, wpk, dw, fw)
     e1.record()
@@ -65,13 +71,14 @@ for i, n in enumerate(names):
     print("%-34s %10.0f %10.0f %10.0f %10.0f" % ((n,) + tuple(d[:, wv, :, i].mean() for wv in range(4))))
 print("%-34s %10.0f %10.0f %10.0f %10.0f" % (("chunk turnaround",) + tuple(gap[:, wv].mean() for wv in range(4))))
 if TAIL:
-    tl = t[ok][:, :, 40:47]
-    tn = ["loop exit -> stores drained (vmcnt 0)", "barrier", "loads -> group 0 normalised", "group 0 MFMAs issued", "groups 1-2 (loads hidden?) issued", "epilogue (residual, stores, stats)"]
+    tl = t[ok][:, :, 40:48 if PIN else 47]
+    tn = ["loop exit -> stores drained (vmcnt 0)", "barrier", "loads -> group 0 normalised", "group 0 MFMAs issued", "groups 1-2 (loads hidden?) issued", "epilogue (residual, stores, stats)"] \
+        + (["project_in (LN, swaps, cuts, 72 MFMAs, 48 stores)"] if PIN else [])
     dt = np.diff(tl, axis=2)
     print("tail: last chunk stamp -> loop exit %.0f clocks" % (tl[:, :, 0] - st[:, :, -1, 7]).mean())
     for i, n in enumerate(tn):
         print("%-40s %10.0f %10.0f %10.0f %10.0f" % ((n,) + tuple(dt[:, wv, i].mean() for wv in range(4))))
-    print("tail total %.0f clocks of a wave life of %.0f" % (dt.sum(axis=2).mean(), (tl[:, :, 6] - meta[:, :, 3]).mean()))
+    print("tail total %.0f clocks of a wave life of %.0f" % (dt.sum(axis=2).mean(), (tl[:, :, -1] - meta[:, :, 3]).mean()))
 tot = d.sum(axis=3).mean(axis=(0, 2))
 bar = d[:, :, :, [1, 3, 5]].sum(axis=3).mean(axis=(0, 2))
 print("per chunk total", np.round(tot), " at barriers", np.round(bar), " share", np.round(bar / tot, 3))
