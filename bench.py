@@ -114,9 +114,11 @@ def _describe_fdsa_fused(c):
 
 
 def _describe_fdsa_fused_tail(c):
-    # the whole sub-block: x in, res in, out + statistics out (the tile-local scratch is not algorithmic traffic); both 1x1 convs' flops
-    B, C, E, H, W = c.i("B", "C", "E", "H", "W")
-    return f"fdn_fdsa_fused_tail[C={C},E={E},{H}x{W}]", 2.0 * B * H * W * (C * 4 * E + 3 * E * C), 4.0 * B * H * W * (3 * C + 4)
+    # the whole sub-block: x in, res in, out + statistics out (the tile-local scratch is not algorithmic traffic); both 1x1 convs' flops;
+    # Hd > 0: plus the following FDFFN's project_in (C -> Hd) and its Hd output planes
+    B, C, E, H, W, Hd = c.i("B", "C", "E", "H", "W", "Hd")
+    return (f"fdn_fdsa_fused_tail[C={C},E={E},{H}x{W},Hd={Hd}]", 2.0 * B * H * W * (C * 4 * E + 3 * E * C + C * Hd),
+            4.0 * B * H * W * (3 * C + 4 + Hd))
 
 
 def _describe_fdsa_full(c):
