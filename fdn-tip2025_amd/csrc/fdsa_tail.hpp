@@ -43,7 +43,16 @@ struct TailIo {
     unsigned P;
     float* h;                // PIN: image base [Hd][P] of the NEXT sub-block's project_in output (FDFFN, FDN_arch.py:456), Hd rows
     int Hd;
+    unsigned* ring_flag;     // ring mode: this workgroup's slot flag (given back when the last wave's read-back has landed) or null
+    int* ring_cnt;           // LDS counter of waves whose read-back has landed
 };
+// the wave whose read-back landed last frees the workgroup's block of the ring (every load of it has returned: the next owner may write)
+__device__ __forceinline__ void tl_ring_release(const TailIo& io) {
+    if (io.ring_flag && (threadIdx.x & 63) == 0) {
+        if (__hip_atomic_fetch_add(io.ring_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 3)
+            __hip_atomic_store(io.ring_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // Level-1 form (E <= 2 SH <= 38, N <= 32): a lane owns two horizontally adjacent pixels (8-byte lanes), a wave two tile rows; fp32 MFMA.
 // Mirrors fdsa_out_vec_kernel<19, 1, true, false, 2, 4, false>.
@@ -123,6 +132,7 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
         }
         if (g == 0) { TLTR(3) }
         if (g == 2) {
+            tl_ring_release(io);                 // (the last group's values are in registers: nothing of the block is read any more)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const fdn_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rr, vo, (unsigned)((r & 3) + 8 * (r >> 2)) * P4, 0);      // 0 without a residual
@@ -253,6 +263,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
     io.scr = tl_uniform_ptr(io_.scr); io.res = tl_uniform_ptr(io_.res); io.y = tl_uniform_ptr(io_.y); io.stats_out = tl_uniform_ptr(io_.stats_out);
     io.E = __builtin_amdgcn_readfirstlane(io_.E); io.N = __builtin_amdgcn_readfirstlane(io_.N); io.W = __builtin_amdgcn_readfirstlane(io_.W);
     io.ty0 = __builtin_amdgcn_readfirstlane(io_.ty0); io.tx0 = __builtin_amdgcn_readfirstlane(io_.tx0); io.P = __builtin_amdgcn_readfirstlane(io_.P);
+    io.h = nullptr; io.Hd = 0; io.ring_flag = tl_uniform_ptr(io_.ring_flag); io.ring_cnt = io_.ring_cnt;
     const float* gimg = tl_uniform_ptr(gimg_);
     constexpr int E2 = 2 * SH, NQ = (SH + 7) / 8;
     const int E = io.E, N = io.N;
@@ -334,6 +345,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
                     nxt[s] = tl_load1(rg[0], voff1, (unsigned)(2 * s) * PIl);
                 }
             }
+            if (g == 2 && rnd == 1) tl_ring_release(io);      // the second row's last group is in registers
 #pragma unroll
             for (int q8 = 0; q8 < NQ; ++q8) {
                 fdn_u32x4 bx[3];
