@@ -653,8 +653,6 @@ def main():
                     "fdn_fdsa_fused + fdn_fdsa_out (DESIGN.md section 4: built, correct, not the default)")
     ap.add_argument("--fdsa-pair", action="store_true", help="A/B: the FDSA sub-blocks of levels 1-2 as fdn_fdsa_fused + fdn_fdsa_out (two launches, the 4E-plane hand-off "
                     "through HBM: the round-5 route) instead of fdn_fdsa_fused_tail")
-    ap.add_argument("--no-ring", action="store_true", help="A/B: fdn_fdsa_fused_tail's tile-local hand-off as one block per tile (every byte written to HBM once per launch) instead of "
-                    "the Infinity-Cache-resident ring of per-resident-workgroup blocks")
     ap.add_argument("--no-tail-pin", action="store_true", help="A/B: the FDFFN project_in of level 1 as its own fdn_conv1x1 launch instead of inside fdn_fdsa_fused_tail")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short side measurements of BASELINE.json configs[2] (1080p B = 4 bf16 storage) "
                     "and configs[4] (LPNet alone) that the default headline run appends as `other_configs`")
@@ -722,7 +720,6 @@ def main():
         fdn_hip.ops.FDSA_FULL = bool(a.fdsa_full)
         fdn_hip.ops.FDSA_TAIL = not a.fdsa_pair
         fdn_hip.ops.FDSA_TAIL_PIN = not a.no_tail_pin
-        fdn_hip.ops.FDSA_RING = not a.no_ring
         if a.narrow_pipe:
             fdn_hip.set_matrix_pipe("bf16-narrow")
         fdn_hip.ops.SPECTRAL_MLP_FUSED = not a.unfused_mlps
@@ -817,7 +814,7 @@ def main():
             and (a.height, a.width) == (720, 1280) and not a.no_parity):
         parity = parity_against_reference(forward, x)
 
-    default_routing = not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.no_ring or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
+    default_routing = not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
 
     def roofline_of(xin, dtype, hw, lpnet_only=False):
         """(roofline of the dominant individual kernel, top 3, the matching committed PMC profile or None) from two instrumented single-stream
@@ -885,7 +882,7 @@ def main():
     # graph, untimed warm-up, K steps between synchronisations), so that every run of the headline command records them too (VERDICT r4, row g)
     other = None
     if (rank == 0 and world == 1 and not a.dry_run and not a.no_other_configs and a.config == "fdn" and a.variant == "lolblur" and a.graph
-            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.no_ring or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
+            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
         from fdn_hip.pipeline import GraphedStep
 
         def side(fn, xin, steps=3):
@@ -960,7 +957,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                        "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "fdsa_pair": bool(a.fdsa_pair), "no_tail_pin": bool(a.no_tail_pin), "no_ring": bool(a.no_ring), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "fdsa_pair": bool(a.fdsa_pair), "no_tail_pin": bool(a.no_tail_pin), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
                        "host_issue_ms_per_step": host_issue_ms, "cpu_affinity_rank0": affinity},
             "whole_path": whole_path_of(a.dtype, P, B, ips / world, dt / a.steps, prof if a.config != "lpnet" else None),
             "roofline": roof, "top_kernels": top, "cpu_baseline": cpu, "other_configs": other,

@@ -602,8 +602,10 @@ struct FusedArgs {
     int N;
     float* h;            // TAIL 3: the following FDFFN's project_in output [B][Hd][H][W]
     int Hd;
-    unsigned* ring;      // TAIL: non-null = `out` is a RING of per-(CU, resident workgroup) blocks and these are its slot flags (FDN_RING_SLOTS words, 0 = free)
 };
+#ifndef FDN_RING
+#define FDN_RING 1          // TAIL kernels: 1 = `out` is a RING of per-(CU, resident workgroup) blocks behind FDN_RING_SLOTS flag words (0 = free); 0 = one block per tile (A/B builds)
+#endif
 // (round 6) The tile-local hand-off as a ring.  With one block per TILE (4.6 GB per launch at level 1) every byte of it is written to HBM once; a
 // workgroup only needs its block for its own lifetime, so the blocks are handed out per RESIDENT workgroup instead - CU (XCC_ID, SE_ID, SH_ID, CU_ID of
 // HW_ID) x the two workgroups a CU holds (80 KB of LDS each) - and rewritten in place: ~80 MB that stay in the 256 MB Infinity Cache (tools/micro/ring_probe.hip).
@@ -615,6 +617,10 @@ constexpr int FDN_RING_HDR = 16384;                // floats in front of the blo
 
 #ifndef FDN_FUSED_WGS
 #define FDN_FUSED_WGS 2
+#endif
+#ifndef FDN_STAGE_OPAQUE
+#define FDN_STAGE_OPAQUE 1      // 1: the tail + project_in kernels (TAIL 3) rebuild stage_fetch's indices per chunk (as C = 64 does) instead of carrying them: carried they
+                                // are spilled there (a scratch reload per chunk behind vmcnt(0)): 3.575 -> 3.525 ms at C = 32, 0.755 -> 0.736 at C = 24 (profiles/r06_tail_ab6*.txt)
 #endif
 #ifndef FDN_FUSED_CELLS
 #define FDN_FUSED_CELLS 1
@@ -668,17 +674,14 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         }
     }
 #endif
-#ifndef FDN_RING
-#define FDN_RING 1          // 0: no ring code in the kernels (A/B builds; the caller must then pass ring = 0)
-#endif
-    __shared__ int ring_s[2];                      // (TAIL, ring) [0] the workgroup's slot, [1] waves whose read-back has landed
+    __shared__ int ring_s[4];                      // (TAIL, ring) [0] the workgroup's slot, [1] waves whose read-back has landed, [2..3] its block's address
     if constexpr (TAIL != 0 && FDN_RING) {
-        if (a.ring && tid == 0) {
+        if (tid == 0) {
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             const unsigned cu = ((xcc & 7u) << 8) | (((hwid >> 13) & 7u) << 5) | (((hwid >> 12) & 1u) << 4) | ((hwid >> 8) & 0xFu);
-            unsigned* f = a.ring + 2 * cu;
+            unsigned* f = reinterpret_cast<unsigned*>(a.out) + 2 * cu;
             int got = -1;
             while (got < 0) {
                 const unsigned o0 = __hip_atomic_exchange(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -694,6 +697,9 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
             }
             ring_s[0] = (int)(2 * cu) + got;
             ring_s[1] = 0;
+            const unsigned long long blk = reinterpret_cast<unsigned long long>(a.out + FDN_RING_HDR + (long)(2 * cu + got) * (4 * a.E * 256));
+            ring_s[2] = (int)(unsigned)blk;
+            ring_s[3] = (int)(unsigned)(blk >> 32);
         }
     }
     // (and: s_setprio 2 / 3 for the prologue - a fresh workgroup's waves are the youngest of their SIMDs - 2.380 / 2.375 against 2.322 ms: slower)
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         //  this change alone cost the C = 32 kernel 2.7 %)
         const int tid_o = tid;
         const int tid = [&] {
-            if constexpr (KST >= 4) { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+            if constexpr (KST >= 4 || (FDN_STAGE_OPAQUE && TAIL == 3)) { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
             else return tid_o;
         }();
         auto tap_of = [&](int i) {                                      // element i < 288: row m = kind * 8 + channel, tap i % 9
@@ -866,10 +872,11 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         __syncthreads();
         FTR(2)
         if constexpr (TAIL != 0 && FDN_RING) {
-            if (a.ring && ch == 0) {            // the slot (taken by thread 0 at entry: its round trip ran under the strip loads) is visible behind this barrier
-                scr_tile = a.out + FDN_RING_HDR + (long)__builtin_amdgcn_readfirstlane(ring_s[0]) * (4 * E * 256);
-                rout = mk_rsrc(scr_tile, 4u * E * 1024u);
-            }
+            // the slot (taken by thread 0 at entry: its round trip ran under the strip loads) is visible behind the first barrier.  Rebuilt per chunk
+            // from the LDS word instead of carried through the loop: a loop-carried descriptor cost the chunk loop three spilled registers
+            scr_tile = reinterpret_cast<const float*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ring_s[3]) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readfirstlane(ring_s[2]));
+            rout = mk_rsrc(scr_tile, 4u * E * 1024u);
         }
 
         // ---- rows: depthwise 3x3 (to_hidden_dw, FDN_arch.py:578) + forward row transforms of q, k, v (v_value: see the column phase)
@@ -1084,7 +1091,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
         io.h = PIN ? a.h + (long)b * a.Hd * P : nullptr;
         io.Hd = a.Hd;
-        io.ring_flag = FDN_RING && a.ring ? a.ring + ring_s[0] : nullptr;
+        io.ring_flag = FDN_RING ? reinterpret_cast<unsigned*>(a.out) + ring_s[0] : nullptr;
         io.ring_cnt = ring_s + 1;
 #ifdef FDN_FUSED_TRACE
         fdsa_tail_px2<SH, PIN>(io, hid, hid + NBLK0 * 256, trc);
@@ -1126,7 +1133,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         io.stats_out = a.stats_out ? a.stats_out + (long)b * 2 * P : nullptr;
         io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
         io.h = nullptr; io.Hd = 0;
-        io.ring_flag = FDN_RING && a.ring ? a.ring + ring_s[0] : nullptr;
+        io.ring_flag = FDN_RING ? reinterpret_cast<unsigned*>(a.out) + ring_s[0] : nullptr;
         io.ring_cnt = ring_s + 1;
 #ifdef FDN_FUSED_TRACE
         fdsa_tail_px1<SH, MT>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw, trc);
@@ -1387,9 +1394,9 @@ extern "C" long fdn_fdsa_tail_pack_floats(int C, int E, int N, int Hd) {
     if (Hd > 0 && !fdsa_tail_pin_ok(form, C, Hd)) return 0;
     return form == 1 ? tl_image_floats(sh, mt) + (Hd > 0 ? tl_pin_floats(3) : 0) : form == 2 ? tl_image_floats_px1(sh, mt) : 0;
 }
-extern "C" long fdn_fdsa_scratch_floats(int B, int E, int H, int W, int ring) {
+extern "C" long fdn_fdsa_scratch_floats(int B, int E, int H, int W) {
     if (B <= 0 || E <= 0 || H <= 0 || W <= 0 || H % 8) return 0;
-    if (ring) return FDN_RING_HDR + (long)FDN_RING_SLOTS * 4 * E * 256;                  // independent of the image: per resident workgroup
+    if (FDN_RING) return FDN_RING_HDR + (long)FDN_RING_SLOTS * 4 * E * 256;             // independent of the image: per resident workgroup
     return (long)B * (H / FT_H) * cdiv(W, FT_W) * 4 * E * 256;
 }
 extern "C" int fdn_fdsa_tail_pack(const float* w, const float* gamma3, const float* beta3, const float* pin_w, const float* pin_b, float* img, int C,
@@ -1412,7 +1419,7 @@ extern "C" int fdn_fdsa_tail_pack(const float* w, const float* gamma3, const flo
 }
 extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
                                    const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, float* h_out, int B,
-                                   int C, int E, int H, int W, int Hd, int ring, fdn_stream_t stream) {
+                                   int C, int E, int H, int W, int Hd, fdn_stream_t stream) {
     FDN_CHECK_ARG(x && wpk && dw_w && fft_w && tail_img && out && scratch && B > 0 && E > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0);
     FDN_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(stats_out) |
@@ -1435,7 +1442,6 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     a.nchunks = (E + FEG - 1) / FEG;
     a.tw = tail_img; a.res = res; a.y = out; a.stats_out = stats_out; a.N = C;
     a.h = h_out; a.Hd = Hd;
-    a.ring = ring ? reinterpret_cast<unsigned*>(scratch) : nullptr;
     const long total = (long)B * a.tiles_per_img;
     FDN_CHECK_ARG(total < 0x7fffffffL);
     const dim3 grid((unsigned)total), block(256);

@@ -294,18 +294,17 @@ def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=F
     B, C, H, W = x.shape
     E = dw_w.shape[0] // 4
     ptr, xbs = _planes(x, "x")
-    ring = int(bool(FDSA_RING))
-    n = lib().fdn_fdsa_scratch_floats(B, E, H, W, ring)
-    key = (str(x.device), n, ring)
+    n = lib().fdn_fdsa_scratch_floats(B, E, H, W)
+    key = (str(x.device), n)
     scr = _fdsa_scratch.get(key)
-    if scr is None:          # (ring: starts with the slot flags - zero once, every launch leaves them zero)
-        scr = _fdsa_scratch[key] = torch.zeros(n, device=x.device, dtype=torch.float32) if ring else torch.empty(n, device=x.device, dtype=torch.float32)
+    if scr is None:          # (a ring of per-resident-workgroup blocks that starts with the slot flags: zero once, every launch leaves them zero)
+        scr = _fdsa_scratch[key] = torch.zeros(n, device=x.device, dtype=torch.float32)
     out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
     st = torch.empty((B, 1, 2, H * W), device=x.device, dtype=torch.float32) if want_stats else None
     h = torch.empty((B, Hd, H, W), device=x.device, dtype=torch.float32) if Hd else None
     rc = lib().fdn_fdsa_fused_tail(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), _flat(wpk, "wpk"), _flat(dw_w, "dw_w"), _flat(fft_w, "fft_w"),
                                    _flat(tail_img, "tail_img"), _flat(res, "res"), _flat(out, "out"), _flat(st, "stats_out"), _flat(scr, "scratch"),
-                                   _flat(h, "h_out"), B, C, E, H, W, Hd, ring, stream())
+                                   _flat(h, "h_out"), B, C, E, H, W, Hd, stream())
     if rc == ERR_UNSUPPORTED:
         return None
     check(rc, "fdn_fdsa_fused_tail")
@@ -316,7 +315,6 @@ def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=F
     return out
 
 
-FDSA_RING = True            # (round 6) the tail's tile-local hand-off lives in a ring of per-resident-workgroup blocks (Infinity-Cache resident) instead of one block per tile
 FDSA_TAIL_PIN = True        # (round 6) level 1: that launch also runs the following FDFFN's project_in (bit-identical to fdn_conv1x1's kernel for the shape)
 FDSA_FULL = False           # True: the whole FDSA sub-block in one launch (fdn_fdsa_full) for C <= FDSA_FULL_MAX_C; False: fdn_fdsa_fused + fdn_fdsa_out
 FDSA_FULL_MAX_C = 32        # measured (tools/ab_fdsa_full.py, B = 8 720p shapes): one launch 3.52 against 3.77 ms at C = 32 and 2.89 against 2.93 at

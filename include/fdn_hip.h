@@ -161,10 +161,10 @@ int fdn_fdsa_full(const float* x, long xbs, const float* stats, const void* wpk,
  * drains its stores, meets at a barrier and then runs fdn_fdsa_out's arithmetic on them itself (L2 / Infinity-Cache read-back of its own bytes:
  * no second launch, no HBM read of the hand-off).  Results equal fdn_fdsa_fused + fdn_fdsa_out bit for bit.
  * fdn_fdsa_tail_pack: project_out w_out [N][3E], gamma3 / beta3 [3E] -> img (fdn_fdsa_tail_pack_floats(C, E, N, Hd) floats; 0 = no in-kernel tail
- *   for this width).  fdn_fdsa_scratch_floats(B, E, H, W, ring): floats of `scratch`.  ring = 0: one block per tile ([B * tiles][4E][8][32], every byte
- *   written to HBM once per launch).  ring = 1: one block per RESIDENT workgroup (compute unit x 2), taken at entry and given back when the tail has
- *   read it - ~80 MB that are rewritten in place and stay in the 256 MB Infinity Cache; the size does not depend on the image, the buffer starts with
- *   the slot flags and MUST BE ZERO-FILLED ONCE by the caller (every launch leaves them zero again); one buffer serves every launch of a stream.
+ *   for this width).  fdn_fdsa_scratch_floats(B, E, H, W): floats of `scratch`: a RING of one block ([4E][8][32] floats) per RESIDENT workgroup
+ *   (compute unit x 2), taken at entry and given back when the tail has read it - ~80 MB in use, rewritten in place, resident in the 256 MB Infinity
+ *   Cache (one block per tile would send 4.6 GB to HBM per launch at level 1).  The size does not depend on the image; the buffer starts with the slot
+ *   flags and MUST BE ZERO-FILLED ONCE by the caller (every launch leaves them zero again); one buffer serves every launch of a stream.
  * fdn_fdsa_fused_tail: x, xbs, stats, wpk, dw_w, fft_w as fdn_fdsa_fused; res [B][C][H][W] or NULL (may be x); out [B][C][H][W] (must not be x);
  *   stats_out [B][2][P] or NULL.  C in {24, 32} with E <= 38 and W even, or C in {48, 64} with E in 39..76 (default matrix-pipe mode only: the
  *   level-2 tail on the bf16 pipe); anything else (and fdn_set_matrix_pipe(1)) returns FDN_ERR_UNSUPPORTED.
@@ -173,12 +173,12 @@ int fdn_fdsa_full(const float* x, long xbs, const float* stats, const void* wpk,
  *   fdn_conv1x1(FDN_PRO_LN) returns for these operands; pin_w [Hd][C] / pin_b [Hd] are the LayerNorm-FOLDED weights (w diag(gamma), w beta) given to
  *   fdn_fdsa_tail_pack.  Hd = 0: pin_w = pin_b = h_out = NULL. */
 long fdn_fdsa_tail_pack_floats(int C, int E, int N, int Hd);
-long fdn_fdsa_scratch_floats(int B, int E, int H, int W, int ring);
+long fdn_fdsa_scratch_floats(int B, int E, int H, int W);
 int fdn_fdsa_tail_pack(const float* w_out, const float* gamma3, const float* beta3, const float* pin_w, const float* pin_b, float* img, int C, int E,
                        int N, int Hd, fdn_stream_t stream);
 int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
                         const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, float* h_out, int B, int C,
-                        int E, int H, int W, int Hd, int ring, fdn_stream_t stream);
+                        int E, int H, int W, int Hd, fdn_stream_t stream);
 
 /* FDSA tail in one launch (FDN_arch.py:633-639 and the residual add of :671): norm1/2/3 over the E channels
  * of out1|out2|out3, times v_value, project_out (3E -> N) + res, and (optionally) the channel LayerNorm

@@ -323,7 +323,7 @@ def test_graph_key_covers_every_routing_switch():
     from fdn_hip import ops, pipeline
     m = torch.nn.Linear(3, 3)
     base = pipeline.weights_signature(m)
-    flips = {"FDSA_FULL": True, "FDSA_FULL_MAX_C": 64, "FDSA_TAIL": False, "FDSA_TAIL_PIN": False, "FDSA_RING": False, "FFN_TAIL_MODE": "split", "SPECTRAL_MLP_FUSED": False,
+    flips = {"FDSA_FULL": True, "FDSA_FULL_MAX_C": 64, "FDSA_TAIL": False, "FDSA_TAIL_PIN": False, "FFN_TAIL_MODE": "split", "SPECTRAL_MLP_FUSED": False,
              "GEMM_OWN_STATS": False, "UPCONV_GATHER": False, "AFF_MULTIRES": False}
     # every module-level switch of ops.py whose initial value is a bool or None (the routing switches; thresholds and width tables are constants)
     import re

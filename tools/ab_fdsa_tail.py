@@ -11,10 +11,6 @@ for a_ in sys.argv[1:]:
         fdn_hip._LIB_PATH = os.path.abspath(a_)          # another build of the library (tools/ab_build.sh)
         print("library:", a_)
 from fdn_hip import ops
-if any("noring" in a_ for a_ in sys.argv[1:]):
-    ops.FDSA_RING = False                 # a -DFDN_RING=0 build: block per tile only
-NORING_LIB = not ops.FDSA_RING
-
 reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 7
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(5)
@@ -79,17 +75,10 @@ def case(B, C, H, W, time_it=True, edge=False):
 
     fused_only = lambda: ops.fdsa_fused(x, stats, wpk, dw, fw)
     res = {"pair": [], "fused_only": [], "one": []}
-    def one_noring(with_pin=False):
-        ops.FDSA_RING = False
-        try:
-            return one(with_pin)
-        finally:
-            ops.FDSA_RING = not NORING_LIB
-    res["one (block per tile)"] = []
-    fs = [("pair", pair), ("fused_only", fused_only), ("one", one), ("one (block per tile)", one_noring)]
+    fs = [("pair", pair), ("fused_only", fused_only), ("one", one)]
     if imgp is not None:
-        res.update({"pair+project_in": [], "one+project_in": [], "one+project_in (block per tile)": []})
-        fs += [("pair+project_in", lambda: pair(True)), ("one+project_in", lambda: one(True)), ("one+project_in (block per tile)", lambda: one_noring(True))]
+        res.update({"pair+project_in": [], "one+project_in": []})
+        fs += [("pair+project_in", lambda: pair(True)), ("one+project_in", lambda: one(True))]
     for _, f in fs:
         timeit(f, 2)
     for _ in range(reps):
