@@ -230,8 +230,22 @@ constexpr unsigned SW_OOB = 0x80000000u;
 // (round 4) The two source planes of a pair live in LDS as ONE plane of (A, B) cells and the taps as (wA, wB) pairs: a window cell is
 // one 8-byte read and both stencils advance in one v_pk_fma_f32 - 36 packed FMAs per pair and lane where there were 72 scalar ones.
 // CODD (odd C: the two channels of a pair read different B planes, FDN_lolv1's 129) keeps a second plane of (A, B1) cells for the odd lanes.
+// (round 6) tools/tail_trace.py: -DFDN_TAILSW_TRACE - every wave of 512 workgroups from the middle of the grid sums the s_memtime clocks it spends in the
+// phases of a pair step (request + taps, window / stencil / GELU / MFMA issue, parking the next pair, barrier) and stamps prologue and epilogue;
+// -DFDN_KOT_GELU / _MFMA / _LOADS / _STENCIL knock a phase out (results are wrong: timing only)
+#ifdef FDN_TAILSW_TRACE
+constexpr int TT_NWG = 512;
+__device__ unsigned long long g_tail_trace[TT_NWG * 4 * 16];
+#define TTR(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
+#else
+#define TTR(var)
+#endif
 template <int MT, int R, bool IBF, bool CODD>
 __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel(FtArgs a) {
+#ifdef FDN_TAILSW_TRACE
+    const unsigned long long tt_entry = __builtin_amdgcn_s_memtime();
+    unsigned long long tt_sum[4] = {0, 0, 0, 0};
+#endif
     constexpr int HRW = 2 * R + 2;                       // halo rows of the tile
     constexpr int PLN = HRW * SW_LS + 4;                 // cells per plane (+ spare cells for the threads without a lane / an edge cell)
     constexpr int NV4 = HRW * 16;                        // float4 of the 64 interior columns
@@ -275,31 +289,50 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
     // an HBM round trip under load several times that), parked in LDS a pair later
     struct Stage { float q4[3][V4T][4], qe[3], pdw, aw[MT]; };
     Stage stg[2];
+    // (round 6) EVERY pair step issues the same loads, unconditionally and without a branch around any of them.  As first written - the request skipped
+    // when pair m + 2 does not exist, the taps and the projection column behind `if (tid < 40)` / `j < C` branches with a zero written first - the
+    // number of loads in flight depended on the path, the compiler's wait-count pass merged the paths to "nothing younger in flight", and every pair
+    // step began with s_waitcnt vmcnt(4) (all of pair m + 1's loads, behind a WAW on the zero) and parked behind vmcnt(0) (pair m + 2's too): the
+    // two-stage prefetch was one of less than a step, and the kernel ran 29 % faster without its loads (tools/tail_trace.py, profiles/r06_tail_mid_trace.txt).
+    // Now a pair that does not exist reads through a descriptor of zero records (returns 0, moves nothing), a lane without a tap / a column reads
+    // outside the descriptor, and the waits count exactly.
+    const rsrc_t rdead = mk_rsrc(a.y, 0u);
+    const rsrc_t rdw = mk_rsrc(a.wdw, (unsigned)(2 * C * 9) * 4u), rwp = mk_rsrc(a.w, (unsigned)(N * C) * 4u);
+    unsigned vdw, vaw[MT];
+    int dw_par;
+    {
+        const int par = tid / 20, i = tid - par * 20, tap = i >> 1;
+        dw_par = par;
+        vdw = (tid < 40 && tap < 9) ? (unsigned)((((i & 1) ? C : 0) + par) * 9 + tap) * 4u : SW_OOB;      // + 72 m: taps of channel 2 m + par, (wA, wB) interleaved
+#pragma unroll
+        for (int t = 0; t < MT; ++t) vaw[t] = (t * 32 + ln < N) ? (unsigned)((t * 32 + ln) * C + kh) * 4u : SW_OOB;      // + 8 m: w[n][2 m + kh]
+    }
     auto fetch = [&](int m, Stage& st) {
         float (&q4)[3][V4T][4] = st.q4;
         float (&qe)[3] = st.qe;
         float& pdw = st.pdw;
         float (&aw_n)[MT] = st.aw;
-        pdw = 0.f;
+#ifdef FDN_KOT_LOADS
+        const bool live = m < 2;
+#else
+        const bool live = m < npairs;                                              // uniform
+#endif
+        const rsrc_t ri = live ? rin : rdead, rd = live ? rdw : rdead, rw_ = live ? rwp : rdead;
         const int j0 = 2 * m, j1 = (2 * m + 1 < C) ? 2 * m + 1 : 2 * m;
         const int pa = m, pb0 = (C + j0) >> 1, pb1 = (C + j1) >> 1;            // grouped conv: output o reads input o / 2
 #pragma unroll
         for (int i = 0; i < V4T; ++i) {
-            st_load4<IBF>(q4[0][i], rin, g4[i], (unsigned)pa * hwi);
-            st_load4<IBF>(q4[1][i], rin, g4[i], (unsigned)pb0 * hwi);
-            if (codd) st_load4<IBF>(q4[2][i], rin, g4[i], (unsigned)pb1 * hwi);
+            st_load4<IBF>(q4[0][i], ri, g4[i], (unsigned)pa * hwi);
+            st_load4<IBF>(q4[1][i], ri, g4[i], (unsigned)pb0 * hwi);
+            if (codd) st_load4<IBF>(q4[2][i], ri, g4[i], (unsigned)pb1 * hwi);
         }
-        qe[0] = st_load1<IBF>(rin, ge, (unsigned)pa * hwi);
-        qe[1] = st_load1<IBF>(rin, ge, (unsigned)pb0 * hwi);
-        if (codd) qe[2] = st_load1<IBF>(rin, ge, (unsigned)pb1 * hwi);
-        if (tid < 40) {                                      // depthwise taps of channels 2m, 2m + 1: [parity][tap](wA, wB)
-            const int par = tid / 20, i = tid - par * 20, j = 2 * m + par;
-            const int tap = i >> 1;
-            pdw = (j < C && tap < 9) ? a.wdw[(long)(((i & 1) ? C : 0) + j) * 9 + tap] : 0.f;
-        }
-        const int j = 2 * m + kh;
+        qe[0] = st_load1<IBF>(ri, ge, (unsigned)pa * hwi);
+        qe[1] = st_load1<IBF>(ri, ge, (unsigned)pb0 * hwi);
+        if (codd) qe[2] = st_load1<IBF>(ri, ge, (unsigned)pb1 * hwi);
+        // depthwise taps of channels 2m, 2m + 1: [parity][tap](wA, wB) on threads 0-39; the projection column of this lane's channel 2m + kh
+        pdw = bload(rd, (!codd || 2 * m + dw_par < C) ? vdw : SW_OOB, (unsigned)(72 * m));
 #pragma unroll
-        for (int t = 0; t < MT; ++t) aw_n[t] = (j < C && t * 32 + ln < N) ? a.w[(long)(t * 32 + ln) * C + j] : 0.f;
+        for (int t = 0; t < MT; ++t) aw_n[t] = bload(rw_, (!codd || 2 * m + kh < C) ? vaw[t] : SW_OOB, (unsigned)(8 * m));
     };
     auto stash = [&](int buf, const Stage& st) {
         const float (&q4)[3][V4T][4] = st.q4;
@@ -326,7 +359,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
             for (int q = 0; q < 16; ++q) acc[i][t][q] = 0.f;
 
     fetch(0, stg[0]);
-    if (npairs > 1) fetch(1, stg[1]);
+    fetch(1, stg[1]);
     float aw[MT], aw_next[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -340,8 +373,8 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
     auto pair_step = [&](int m, Stage& mine, const Stage& nxt) {
         // `mine` held pair m (already parked in LDS, its registers are free): refill it with pair m + 2; `nxt` holds pair m + 1
         const int buf = m & 1;
-        const bool more = m + 1 < npairs;
-        if (m + 2 < npairs) fetch(m + 2, mine);
+        TTR(tt0)
+        fetch(m + 2, mine);
         // taps of this lane's channel
         fdn_f32x2 wab[9];
         {
@@ -360,6 +393,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         load_row(0, 0);
         load_row(1, 1);
         load_row(2, 2);
+        TTR(tt1)
 #ifndef FDN_GELU_SCALAR
         static_assert(R % 2 == 0, "rows are gated in pairs");
 #pragma unroll
@@ -373,15 +407,30 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) sAB[h2] = __builtin_elementwise_fma(wab[dy * 3 + dx], wAB[(ii + dy) & 3][dx], sAB[h2]);
+                    for (int dx = 0; dx < 3; ++dx) {
+#ifdef FDN_KOT_STENCIL
+                        if (dy != 1 || dx != 1) continue;
+#endif
+                        sAB[h2] = __builtin_elementwise_fma(wab[dy * 3 + dx], wAB[(ii + dy) & 3][dx], sAB[h2]);
+                    }
             }
+#ifdef FDN_KOT_GELU
+            const fdn_f32x2 val = fdn_f32x2{sAB[0].x, sAB[1].x} * fdn_f32x2{sAB[0].y, sAB[1].y};
+#else
             const fdn_f32x2 val = gelu_fast2(fdn_f32x2{sAB[0].x, sAB[1].x}) * fdn_f32x2{sAB[0].y, sAB[1].y};      // gelu(x1) * x2, FDN_arch.py:473 / :427
+#endif
+#ifdef FDN_KOT_MFMA
+            acc[i][0][0] += val.x * aw[0];
+            acc[i + 1][0][0] += val.y * aw[0];
+#else
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val.x, acc[i][t], 0, 0, 0);
                 acc[i + 1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val.y, acc[i + 1][t], 0, 0, 0);
             }
+#endif
         }
+        TTR(tt2)
 #else
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -396,17 +445,30 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
             for (int t = 0; t < MT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val, acc[i][t], 0, 0, 0);
         }
 #endif
-        if (more) {
-            stash(buf ^ 1, nxt);                             // (that half was last read two pairs ago, behind the previous barrier)
+        stash(buf ^ 1, nxt);                                 // (that half was last read two pairs ago, behind the previous barrier; behind the last pair: zeros)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) aw[t] = nxt.aw[t];
-        }
+        for (int t = 0; t < MT; ++t) aw[t] = nxt.aw[t];
+        TTR(tt3)
         __syncthreads();
+#ifdef FDN_TAILSW_TRACE
+        const unsigned long long tt4 = __builtin_amdgcn_s_memtime();
+        tt_sum[0] += tt1 - tt0; tt_sum[1] += tt2 - tt1; tt_sum[2] += tt3 - tt2; tt_sum[3] += tt4 - tt3;
+#endif
     };
-    for (int m = 0; m < npairs; m += 2) {
-        pair_step(m, stg[0], stg[1]);
-        if (m + 1 < npairs) pair_step(m + 1, stg[1], stg[0]);
+#ifdef FDN_TAILSW_TRACE
+    const unsigned long long tt_loop = __builtin_amdgcn_s_memtime();
+#endif
+    {
+        int m = 0;
+        for (; m + 1 < npairs; m += 2) {                      // two steps per trip, no branch between them: the loads in flight are the same on every path
+            pair_step(m, stg[0], stg[1]);
+            pair_step(m + 1, stg[1], stg[0]);
+        }
+        if (m < npairs) pair_step(m, stg[0], stg[1]);
     }
+#ifdef FDN_TAILSW_TRACE
+    const unsigned long long tt_epi = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue: residual, store, next LayerNorm's statistics ----------------------------------------------------------
     const int gx = tx0 + col;
@@ -455,6 +517,18 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
             }
         }
     }
+#ifdef FDN_TAILSW_TRACE
+    {
+        const unsigned rel = blockIdx.x - gridDim.x / 2;
+        if (rel < (unsigned)TT_NWG && lane == 0) {
+            unsigned long long* t = g_tail_trace + ((long)rel * 4 + wave) * 16;
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            t[0] = tt_loop - tt_entry; t[1] = tt_sum[0]; t[2] = tt_sum[1]; t[3] = tt_sum[2]; t[4] = tt_sum[3];
+            t[5] = __builtin_amdgcn_s_memtime() - tt_epi; t[6] = tt_epi - tt_loop; t[7] = hwid; t[8] = (unsigned long long)npairs;
+        }
+    }
+#endif
 }
 
 template <int MT, int R, bool IBF>
@@ -481,6 +555,15 @@ int launch(FtArgs a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef FDN_TAILSW_TRACE
+extern "C" int fdn_debug_tail_trace(void* host, long bytes, int clear) {          // trace builds only (tools/tail_trace.py); not part of the ABI
+    static unsigned long long z[TT_NWG * 4 * 16];
+    if (bytes > (long)sizeof(z)) return FDN_ERR_ARG;
+    if (clear) return hipMemcpyToSymbol(HIP_SYMBOL(g_tail_trace), z, sizeof(z), 0, hipMemcpyHostToDevice) == hipSuccess ? FDN_OK : FDN_ERR_LAUNCH;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? FDN_OK : FDN_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int fdn_ffn_tail(const void* y_, const float* dw_w, const float* w, const float* res, float* out, float* stats_out,
                             int B, int C, int N, int H, int W, int y_bf16, int form, fdn_stream_t stream) {

@@ -276,6 +276,16 @@ constexpr int CPB_MIN = 4, CPB_MAX = 22;
 constexpr int HALO2 = (TH + 4) * (TW + 4);
 constexpr int HPT2 = (HALO2 + 255) / 256;               // 10 elements per thread
 
+// (round 6) tools/tail_trace.py mid: -DFDN_MID_TRACE - per wave, summed over its channels, the s_memtime clocks of phase A (ring conv + GELU + forward
+// rows), barrier, B (park the next halo + columns), barrier, C (inverse rows + second conv + stores), barrier; -DFDN_KOM_GELU / _CONV2 / _COLS / _STORE /
+// _LOADS knock a piece out (results are wrong: timing only)
+#ifdef FDN_MID_TRACE
+constexpr int MT_NWG = 512;
+__device__ unsigned long long g_mid_trace[MT_NWG * 4 * 16];
+#define MTR(var) const unsigned long long var = __builtin_amdgcn_s_memtime();
+#else
+#define MTR(var)
+#endif
 template <bool V4, bool IBF, bool OBF>      // IBF / OBF: x / out are stored as bf16 (fp32 math either way; V4 needs fp32 input)
 #ifndef FDN_MID_WGS
 #define FDN_MID_WGS 3
@@ -292,6 +302,11 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
     __shared__ float mid[(TH + 2) * LSM];           // gelu(dw0(x)) on halo 1
     __shared__ __attribute__((aligned(16))) float2 S[NP * PS];
     __shared__ float2 filt[40];                     // ffta * e^{-i fftp} per (ky, kx)
+#ifdef FDN_MID_TRACE
+    const unsigned long long mt_entry = __builtin_amdgcn_s_memtime();
+    unsigned long long mt_sum[6] = {0, 0, 0, 0, 0, 0};
+    int mt_nch = 0;
+#endif
 
     const int tid = threadIdx.x;
     const int ngroups = (Hd + CPB - 1) / CPB;
@@ -343,17 +358,27 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
             slotp[i] = idx < NPAIR ? r * LS2 + 2 * cp : (TH + 4) * LS2;
         }
     }
-    auto fetch = [&](int c) {
+    // (round 6) The loop issues the SAME loads on every path: a channel that does not exist is requested through a descriptor of zero records (returns 0,
+    // moves nothing).  With the request inside `if (more)` the compiler's wait-count pass merged the two paths to "nothing younger in flight": the top of
+    // every channel waited for one of the two stores just issued (vmcnt(1) in front of the halo request) and wave 0, which builds the filter, for both
+    // (vmcnt(0)) - the kernel ran 19 % faster without its stores (tools/tail_trace.py, profiles/r06_tail_mid_trace.txt).
+    const rsrc_t rdead = mk_rsrc(x, 0u);
+    const rsrc_t rfa = mk_rsrc(ffta, (unsigned)Hd * 160u), rfp = mk_rsrc(fftp, (unsigned)Hd * 160u);
+    auto fetch = [&](int c, bool live) {
+#ifdef FDN_KOM_LOADS
+        live = live && c == cbase;
+#endif
+        const rsrc_t ri = live ? rin : rdead;
         // (the plane offset must reach the loads in a scalar register: the compiler keeps the strength-reduced c * hw4 of the channel loop in a
         //  VECTOR register and then wraps every load in a waterfall loop - 12 per channel, tools/isa_waterfall.py)
         const unsigned po = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)c * hw4));
-        if (V4) { halo_v4_fetch(rin, po, hv, hd); return; }
+        if (V4) { halo_v4_fetch(ri, po, hv, hd); return; }
         if constexpr (IBF) {
 #pragma unroll
-            for (int i = 0; i < HPP; ++i) prep[i] = __builtin_amdgcn_raw_buffer_load_b32(rin, goffp[i], po, 0);
+            for (int i = 0; i < HPP; ++i) prep[i] = __builtin_amdgcn_raw_buffer_load_b32(ri, goffp[i], po, 0);
         } else {
 #pragma unroll
-            for (int i = 0; i < HPT2; ++i) pre[i] = st_load1<IBF>(rin, goff[i], po);
+            for (int i = 0; i < HPT2; ++i) pre[i] = st_load1<IBF>(ri, goff[i], po);
         }
     };
     auto stash = [&]() {
@@ -369,28 +394,35 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
             for (int i = 0; i < HPT2; ++i) tin[slot[i]] = pre[i];   // unconditional (spare cell for slots past the tile)
         }
     };
-    fetch(cbase);
+    fetch(cbase, true);
     stash();
-    __syncthreads();
-
     // (ffta, fftp) of the NEXT channel travel with its halo: loaded right here, in the middle of the loop, they would be
     // waited for with vmcnt(0), which also drains the halo prefetch issued just before (the counter is in-order)
-    const int ftid = tid < 40 ? tid : 0;
-    float fa = ffta[cbase * 40 + ftid], fp = fftp[cbase * 40 + ftid];
-    const bool ring_inside = ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + TW + 1 <= W;
-    for (int ci = 0; ci < CPB; ++ci) {
-        const int c = cbase + ci;
-        if (c >= Hd) break;                                   // uniform
-        const bool more = ci + 1 < CPB && c + 1 < Hd;
+    const unsigned ftoff = tid < 40 ? (unsigned)tid * 4u : OOB;
+    float fa = bload(rfa, ftoff, (unsigned)cbase * 160u), fp = bload(rfp, ftoff, (unsigned)cbase * 160u);
+    // the filter ffta e^{-i fftp} of a channel is built one channel ahead, in phase C of its predecessor (the first one here): at the top of the loop
+    // it would wait for (fa, fp) with everything younger - the stores just issued - in front of it
+    auto build_filter = [&]() {
         if (tid < 40) {
             float sn, cs;
             fdn_sincos(fp, &sn, &cs);
             filt[tid] = make_float2(fa * cs, -fa * sn);
         }
-        if (more) {
-            fetch(c + 1);                                     // next channel's halo flies during this one's math
-            fa = ffta[(c + 1) * 40 + ftid];
-            fp = fftp[(c + 1) * 40 + ftid];
+    };
+    build_filter();
+    __syncthreads();
+    const bool ring_inside = ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + TW + 1 <= W;
+    for (int ci = 0; ci < CPB; ++ci) {
+        const int c = cbase + ci;
+        if (c >= Hd) break;                                   // uniform
+        const bool more = ci + 1 < CPB && c + 1 < Hd;
+        MTR(mt0)
+        {
+            fetch(c + 1, more);                               // next channel's halo flies during this one's math
+            const rsrc_t ra = more ? rfa : rdead, rp = more ? rfp : rdead;
+            const unsigned fo = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(c + 1) * 160u));
+            fa = bload(ra, ftoff, fo);
+            fp = bload(rp, ftoff, fo);
         }
         float k0[9], k2[9];
 #pragma unroll
@@ -420,7 +452,11 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
             if (ring_inside) {                                    // uniform: the whole ring of this tile lies in the image (all but border tiles)
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {                  // GELU on pairs: packed fp32 for the polynomial and the products
+#ifdef FDN_KOM_GELU
+                    const fdn_f32x2 gv = fdn_f32x2{o8[j], o8[j + 1]};
+#else
                     const fdn_f32x2 gv = gelu_fast2(fdn_f32x2{o8[j], o8[j + 1]});
+#endif
                     mid[r * LSM + c0 + j] = gv.x;
                     mid[r * LSM + c0 + j + 1] = gv.y;
                 }
@@ -471,13 +507,19 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx) S[patch * PS + kx * KXS + rr] = o[kx];
         }
+        MTR(mt1)
         __syncthreads();
+        MTR(mt2)
 
         // ---- B: tin is free: park the prefetched halo; second conv; column transforms --------------
-        if (more) stash();
+        stash();                                                  // (behind the last channel: zeros, read by nobody)
         auto second_conv = [&](float (&sp)[8]) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) sp[j] = 0.f;
+#ifdef FDN_KOM_CONV2
+            sp[0] = mid[(py * 8 + rr) * LSM + px * 8];
+            return;
+#endif
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 float v[10];
@@ -494,7 +536,11 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
         second_conv(sp);
 #endif
         // columns: forward, z * ffta * e^{-i fftp}, inverse  (FDN_arch.py:460-469)
+#ifdef FDN_KOM_COLS
+        if (false) {
+#else
         if (tid < NP * 5) {
+#endif
             const int pj = tid / 5, kx = tid - pj * 5;
             float2 z[8];
 #pragma unroll
@@ -533,9 +579,12 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #pragma unroll
             for (int i = 0; i < 8; ++i) S[pj * PS + kx * KXS + i] = make_float2(z[i].x * sc, z[i].y * sc);
         }
+        MTR(mt3)
         __syncthreads();
+        MTR(mt4)
 
         // ---- C: inverse rows + spatial branch, 32-byte segments to global --------------------------------
+        if (more) build_filter();                                 // the columns of this channel are done with `filt`; (fa, fp) of channel c + 1 landed long ago
         {
             float2 xk[5];
 #pragma unroll
@@ -548,10 +597,33 @@ __global__ __launch_bounds__(256, FDN_MID_WGS) void fdffn_mid_kernel(const float
 #endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[j] += sp[j];                                                              // :470
+#ifdef FDN_KOM_STORE
+            if (r[0] == 123.456f)
+#endif
             st_store8<OBF>(r, rout, ooff, (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)c * hwo)));
         }
+        MTR(mt5)
         __syncthreads();                                          // S, mid, filt are rewritten by the next channel
+#ifdef FDN_MID_TRACE
+        {
+            const unsigned long long mt6 = __builtin_amdgcn_s_memtime();
+            mt_sum[0] += mt1 - mt0; mt_sum[1] += mt2 - mt1; mt_sum[2] += mt3 - mt2; mt_sum[3] += mt4 - mt3; mt_sum[4] += mt5 - mt4; mt_sum[5] += mt6 - mt5;
+            ++mt_nch;
+        }
+#endif
     }
+#ifdef FDN_MID_TRACE
+    {
+        const unsigned rel = blockIdx.x - gridDim.x / 2;
+        if (rel < (unsigned)MT_NWG && (tid & 63) == 0) {
+            unsigned long long* t = g_mid_trace + ((long)rel * 4 + (tid >> 6)) * 16;
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i] = mt_sum[i];
+            t[6] = (unsigned long long)mt_nch; t[7] = now - mt_entry;
+        }
+    }
+#endif
 }
 
 
@@ -1475,6 +1547,14 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     return fdn_launch_status();
 }
 
+#ifdef FDN_MID_TRACE
+extern "C" int fdn_debug_mid_trace(void* host, long bytes, int clear) {          // trace builds only (tools/tail_trace.py); not part of the ABI
+    static unsigned long long z[MT_NWG * 4 * 16];
+    if (bytes > (long)sizeof(z)) return FDN_ERR_ARG;
+    if (clear) return hipMemcpyToSymbol(HIP_SYMBOL(g_mid_trace), z, sizeof(z), 0, hipMemcpyHostToDevice) == hipSuccess ? FDN_OK : FDN_ERR_LAUNCH;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mid_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? FDN_OK : FDN_ERR_LAUNCH;
+}
+#endif
 #ifdef FDN_FUSED_TRACE
 extern "C" int fdn_debug_fused_trace(void* host, long bytes) {          // trace builds only (tools/fused_trace.py); not part of the ABI
     if (bytes > (long)sizeof(unsigned long long) * FT_NWG * 4 * 64) return FDN_ERR_ARG;
