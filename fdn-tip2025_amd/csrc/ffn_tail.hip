@@ -241,7 +241,7 @@ __device__ unsigned long long g_tail_trace[TT_NWG * 4 * 16];
 #define TTR(var)
 #endif
 template <int MT, int R, bool IBF, bool CODD>
-__global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel(FtArgs a) {
+__global__ __launch_bounds__(256, (R * MT <= 8 && !(IBF && CODD && MT == 2)) ? 2 : 1) void ffn_tail_sw_kernel(FtArgs a) {      // (bf16 input, odd C, N = 64 - FDN_lolv1's level 2 in bf16 mode - needs > 256 registers: one workgroup per CU rather than 227 spilled)
 #ifdef FDN_TAILSW_TRACE
     const unsigned long long tt_entry = __builtin_amdgcn_s_memtime();
     unsigned long long tt_sum[4] = {0, 0, 0, 0};
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
     constexpr unsigned IES = st_bytes<IBF>();
     __shared__ __attribute__((aligned(16))) fdn_f32x2 planes[2][NPL][PLN];
     __shared__ __attribute__((aligned(16))) fdn_f32x2 dwl[2][2][10];      // [buffer][k parity][tap] = (wA, wB)
+    __shared__ float wl[2][2][MT * 32];                                     // [buffer][k parity][output channel]: the projection's column pair w[n][2m], w[n][2m + 1]
 
     const int C = a.C, N = a.N, H = a.H, W = a.W;
     const unsigned P = (unsigned)H * W, hwi = P * IES, hw4 = P * 4u;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
     }
     // two register stages: the planes of pair m + 2 are requested while pair m is evaluated (one pair of arithmetic is ~0.4 us,
     // an HBM round trip under load several times that), parked in LDS a pair later
-    struct Stage { float q4[3][V4T][4], qe[3], pdw, aw[MT]; };
+    struct Stage { float q4[3][V4T][4], qe[3], pdw, pw; };
     Stage stg[2];
     // (round 6) EVERY pair step issues the same loads, unconditionally and without a branch around any of them.  As first written - the request skipped
     // when pair m + 2 does not exist, the taps and the projection column behind `if (tid < 40)` / `j < C` branches with a zero written first - the
@@ -298,20 +299,23 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
     // outside the descriptor, and the waits count exactly.
     const rsrc_t rdead = mk_rsrc(a.y, 0u);
     const rsrc_t rdw = mk_rsrc(a.wdw, (unsigned)(2 * C * 9) * 4u), rwp = mk_rsrc(a.w, (unsigned)(N * C) * 4u);
-    unsigned vdw, vaw[MT];
-    int dw_par;
+    // two small values per thread and pair travel with the planes and are parked in LDS with them: threads 0-39 a depthwise tap, threads 64 .. a
+    // projection weight w[n][2 m + par] (a lane reads its own column from LDS at the top of the step - as a per-lane global load carried to the next
+    // trip in a register it cost a register copy behind vmcnt(0) at the loop's back edge, i.e. a full drain of the prefetch every second step)
+    unsigned vdw, vpw;
+    int dw_par, pw_par;
     {
         const int par = tid / 20, i = tid - par * 20, tap = i >> 1;
         dw_par = par;
         vdw = (tid < 40 && tap < 9) ? (unsigned)((((i & 1) ? C : 0) + par) * 9 + tap) * 4u : SW_OOB;      // + 72 m: taps of channel 2 m + par, (wA, wB) interleaved
-#pragma unroll
-        for (int t = 0; t < MT; ++t) vaw[t] = (t * 32 + ln < N) ? (unsigned)((t * 32 + ln) * C + kh) * 4u : SW_OOB;      // + 8 m: w[n][2 m + kh]
+        const int u = tid - 64, n = u % (MT * 32);
+        pw_par = u / (MT * 32);
+        vpw = (u >= 0 && u < 2 * MT * 32 && n < N) ? (unsigned)(n * C + pw_par) * 4u : SW_OOB;            // + 8 m: w[n][2 m + par] (threads 64 ..)
     }
     auto fetch = [&](int m, Stage& st) {
         float (&q4)[3][V4T][4] = st.q4;
         float (&qe)[3] = st.qe;
         float& pdw = st.pdw;
-        float (&aw_n)[MT] = st.aw;
 #ifdef FDN_KOT_LOADS
         const bool live = m < 2;
 #else
@@ -329,10 +333,9 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         qe[0] = st_load1<IBF>(ri, ge, (unsigned)pa * hwi);
         qe[1] = st_load1<IBF>(ri, ge, (unsigned)pb0 * hwi);
         if (codd) qe[2] = st_load1<IBF>(ri, ge, (unsigned)pb1 * hwi);
-        // depthwise taps of channels 2m, 2m + 1: [parity][tap](wA, wB) on threads 0-39; the projection column of this lane's channel 2m + kh
+        // depthwise taps of channels 2m, 2m + 1 ([parity][tap](wA, wB), threads 0-39) / the projection's columns 2m, 2m + 1 (waves 1 .. MT)
         pdw = bload(rd, (!codd || 2 * m + dw_par < C) ? vdw : SW_OOB, (unsigned)(72 * m));
-#pragma unroll
-        for (int t = 0; t < MT; ++t) aw_n[t] = bload(rw_, (!codd || 2 * m + kh < C) ? vaw[t] : SW_OOB, (unsigned)(8 * m));
+        st.pw = bload(rw_, (!codd || 2 * m + pw_par < C) ? vpw : SW_OOB, (unsigned)(8 * m));
     };
     auto stash = [&](int buf, const Stage& st) {
         const float (&q4)[3][V4T][4] = st.q4;
@@ -348,6 +351,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
             planes[buf][pl][se] = fdn_f32x2{qe[0], qe[1 + pl]};
         }
         if (tid < 40) reinterpret_cast<float*>(dwl[buf][tid / 20])[tid % 20] = pdw;
+        if (tid >= 64 && tid < 64 + 2 * MT * 32) (&wl[buf][0][0])[tid - 64] = st.pw;
     };
 
     f32x16 acc[R][MT];
@@ -360,12 +364,6 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
 
     fetch(0, stg[0]);
     fetch(1, stg[1]);
-    float aw[MT], aw_next[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        aw[t] = stg[0].aw[t];
-        aw_next[t] = stg[1].aw[t];
-    }
     stash(0, stg[0]);
     __syncthreads();
 
@@ -375,12 +373,15 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         const int buf = m & 1;
         TTR(tt0)
         fetch(m + 2, mine);
-        // taps of this lane's channel
+        // taps and projection column of this lane's channel
         fdn_f32x2 wab[9];
+        float aw[MT];
         {
             const fdn_f32x2* dp = dwl[buf][kh];
 #pragma unroll
             for (int i = 0; i < 9; ++i) wab[i] = dp[i];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) aw[t] = wl[buf][kh][t * 32 + ln];
         }
         const fdn_f32x2* pAB = planes[buf][(codd && kh) ? NPL - 1 : 0] + r0 * SW_LS + 3 + col;
         // window rows live in a ring of four: row i + 3 is requested while row i (rows i .. i + 2) is evaluated, so the LDS
@@ -446,8 +447,6 @@ __global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_sw_kernel
         }
 #endif
         stash(buf ^ 1, nxt);                                 // (that half was last read two pairs ago, behind the previous barrier; behind the last pair: zeros)
-#pragma unroll
-        for (int t = 0; t < MT; ++t) aw[t] = nxt.aw[t];
         TTR(tt3)
         __syncthreads();
 #ifdef FDN_TAILSW_TRACE
