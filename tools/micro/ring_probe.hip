@@ -7,9 +7,10 @@
 #include <cstdio>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr int BLK = 152 * 1024;                       // bytes per tile block (4E planes x 1 KB, E = 38)
-template <bool RING, bool READ>
-__global__ __launch_bounds__(256, 2) void k(char* buf, int rounds, unsigned* sink) {
+// BLK: bytes per tile block - 152 KB = 4E planes x 1 KB at level 1 (E = 38, two workgroups per CU); 612 KB = the 612 planes of a level-3 tile
+// (E = 153, VERDICT r5 item 5: one workgroup per CU walking all 20 channel groups of an 8 x 32 tile and feeding the LN3 GEMM from its own block)
+template <bool RING, bool READ, int BLK, int WGS>
+__global__ __launch_bounds__(256, WGS) void k(char* buf, int rounds, unsigned* sink) {
     const int tid = threadIdx.x;
     unsigned acc = 0;
     for (int r = 0; r < rounds; ++r) {
@@ -30,9 +31,10 @@ __global__ __launch_bounds__(256, 2) void k(char* buf, int rounds, unsigned* sin
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-int main() {
+template <int BLK, int WGS>
+void probe(int rounds) {
     hipDeviceProp_t pr; hipGetDeviceProperties(&pr, 0);
-    const int grid = pr.multiProcessorCount * 2, rounds = 57;
+    const int grid = pr.multiProcessorCount * WGS;
     char* buf; unsigned* sink;
     const size_t big = (size_t)grid * rounds * BLK;
     hipMalloc(&buf, big); hipMalloc(&sink, 64);
@@ -49,10 +51,16 @@ int main() {
         const double gb = (double)grid * rounds * BLK / 1e9;
         printf("%-44s %.3f ms   %.2f GB written%s  -> %.2f TB/s per direction\n", name, best, gb, "", gb / best);
     };
-    printf("grid %d workgroups x %d rounds x %d KB\n", grid, rounds, BLK / 1024);
-    run("fresh blocks (4.6 GB), write only", k<false, false>);
-    run("ring (80 MB rewritten), write only", k<true, false>);
-    run("fresh blocks, write + same-workgroup read-back", k<false, true>);
-    run("ring, write + same-workgroup read-back", k<true, true>);
+    printf("grid %d workgroups (%d per CU) x %d rounds x %d KB: ring %.0f MB, fresh %.2f GB\n", grid, WGS, rounds, BLK / 1024, grid * (double)BLK / 1e6, big / 1e9);
+    run("fresh blocks, write only", k<false, false, BLK, WGS>);
+    run("ring (rewritten in place), write only", k<true, false, BLK, WGS>);
+    run("fresh blocks, write + same-workgroup read-back", k<false, true, BLK, WGS>);
+    run("ring, write + same-workgroup read-back", k<true, true, BLK, WGS>);
+    hipFree(buf); hipFree(sink);
+}
+int main() {
+    probe<152 * 1024, 2>(57);          // level 1: 80 MB in flight
+    probe<612 * 1024, 1>(14);          // level 3, one workgroup per CU: 160 MB in flight
+    probe<612 * 1024, 2>(7);           // level 3, two per CU: 321 MB in flight (beyond the Infinity Cache)
     return 0;
 }
