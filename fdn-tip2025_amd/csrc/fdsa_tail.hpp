@@ -30,6 +30,16 @@ __device__ __forceinline__ float tl_xsum32(float v) { return v + __shfl_xor(v, 3
 __device__ __forceinline__ fdn_f32x2 tl_rsqrt_eps(fdn_f32x2 v) { return fdn_f32x2{1.0f / sqrtf(v.x + 1e-5f), 1.0f / sqrtf(v.y + 1e-5f)}; }
 __device__ __forceinline__ float tl_rsqrt_eps(float v) { return 1.0f / sqrtf(v + 1e-5f); }
 
+// (dl * dl rounded, then added: fdsa_out_vec_kernel's select between the product and the sum keeps the two apart; without the select - FULL: every
+// channel of the group exists - the compiler would contract them into one fma and the statistics would round differently)
+template <bool FULL, typename T>
+__device__ __forceinline__ T tl_sq_acc(T q, T dl, bool live) {
+#pragma clang fp contract(off)
+    const T p = dl * dl;
+    if constexpr (FULL) return q + p;
+    else return q + (live ? p : T(0.f));
+}
+
 // operand image of the tail in LDS / global (fdn_fdsa_tail_pack): gamma [3][E2] | beta [3][E2] | Wl [3][E2][WS], E2 = 2 ceil(E / 2), WS = 32 MT + 1,
 // padded to whole KB (one LDS-DMA wave instruction moves 64 lanes x 16 bytes)
 __host__ __device__ constexpr int tl_image_floats(int SH, int MT) { return ((6 * 2 * SH + 3 * 2 * SH * (MT * 32 + 1) + 255) / 256) * 256; }
@@ -67,7 +77,8 @@ __device__ __forceinline__ void tl_ring_release(const TailIo& io) {
 // order: the same bits), and the C-plane read + LayerNorm + split of that launch are gone.  An MFMA result has channels (r & 3) + 8 (r >> 2) + 4 kh in
 // register r, its B operand wants channels 16 ks + 8 kh + j: four v_permlane32_swap per 16 channels move the two middle quarters across the lane halves.
 // lds_pin: [NT tiles][2 k-steps][3 parts][64 lanes] 16-byte A operands of the LayerNorm-folded weights, then NT * 32 bias floats.
-template <int SH, bool PIN = false, int NT = 3>
+// FULL: E == 2 SH and N == 32 (the stock level 1: E = 38, C = 32) - no channel-range predicates (205 selects + 36 compares of the 1,350 vector instructions)
+template <int SH, bool PIN = false, int NT = 3, bool FULL = false>
 __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds, const float* lds_pin = nullptr, unsigned long long* trc = nullptr) {
     typedef fdn_f32x2 T;
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -121,7 +132,7 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
 #pragma unroll
         for (int s = 0; s < SH; ++s) {
             const T dl = cur[s] - m;
-            q += (2 * s + kh < E) ? dl * dl : T(0.f);
+            q = tl_sq_acc<FULL>(q, dl, 2 * s + kh < E);
         }
         const T rs = tl_rsqrt_eps(tl_xsum32(q) * invE);
 #pragma unroll
@@ -157,7 +168,7 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
         T o = T{acc[0][r], acc[1][r]};
         o += rres[r];
         __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(o.x), __float_as_uint(o.y)}, ro, vo, (unsigned)nrow * P4, 0);
-        outv[r] = (nrow + 4 * kh < N) ? o : T(0.f);
+        outv[r] = (FULL || nrow + 4 * kh < N) ? o : T(0.f);
         sm += outv[r];
     }
     if (io.stats_out || PIN) {
@@ -166,7 +177,7 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const T dl = outv[r] - mean;
-            sq += ((r & 3) + 8 * (r >> 2) + 4 * kh < N) ? dl * dl : T(0.f);
+            sq = tl_sq_acc<FULL>(sq, dl, (r & 3) + 8 * (r >> 2) + 4 * kh < N);
         }
         const T rstd = tl_rsqrt_eps(tl_xsum32(sq) / (float)N);
         if (io.stats_out && kh == 0) {
