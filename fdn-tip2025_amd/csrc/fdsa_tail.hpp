@@ -266,7 +266,7 @@ __device__ __forceinline__ Tp* tl_uniform_ptr(Tp* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<Tp*>(((unsigned long long)hi << 32) | lo);
 }
-template <int SH, int MT>
+template <int SH, int MT, bool FULL = false>          // FULL: E == 2 SH and N == 32 MT (the stock level 2: E = 76, C = 64): no channel-range predicates
 __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb, lds_cu4 W0, lds_cu4 W1, const float* gimg_,
                                               unsigned long long* trc = nullptr) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -338,7 +338,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
 #pragma unroll
             for (int s = 0; s < SH; ++s) {
                 const float dl = cur[s] - m;
-                q += (2 * s + khl < E) ? dl * dl : 0.f;
+                q = tl_sq_acc<FULL>(q, dl, 2 * s + khl < E);
             }
             const float rs = tl_rsqrt_eps(tl_xsum32(q) * invE);
 #pragma unroll
@@ -406,7 +406,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
                 float o = acc[mt][r];
                 o += rres[mt][r];
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, vo, (unsigned)nrow * P4l, 0);
-                outv[mt][r] = (nrow + 4 * khl < N) ? o : 0.f;
+                outv[mt][r] = (FULL || nrow + 4 * khl < N) ? o : 0.f;
                 sm += outv[mt][r];
             }
         if (io.stats_out) {
@@ -417,7 +417,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float dl = outv[mt][r] - mean;
-                    sq += (mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khl < N) ? dl * dl : 0.f;
+                    sq = tl_sq_acc<FULL>(sq, dl, mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khl < N);
                 }
             const float rstd = tl_rsqrt_eps(tl_xsum32(sq) / (float)N);
             if (kh == 0) {

@@ -1210,9 +1210,9 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         io.ring_flag = FDN_RING ? reinterpret_cast<unsigned*>(a.out) + ring_s[0] : nullptr;
         io.ring_cnt = ring_s + 1;
 #ifdef FDN_FUSED_TRACE
-        fdsa_tail_px1<SH, MT>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw, trc);
+        fdsa_tail_px1<SH, MT, C == 64>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw, trc);
 #else
-        fdsa_tail_px1<SH, MT>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw);
+        fdsa_tail_px1<SH, MT, C == 64>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw);      // (C = 64 is always the stock E = 76: checked by the launcher)
 #endif
     }
 }
@@ -1504,7 +1504,7 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     int sh, mt;
     const int form = fdsa_tail_form(C, E, C, &sh, &mt);
     if (!form || (form == 1 && W % 2)) return FDN_ERR_UNSUPPORTED;
-    if (C == 32 && E != 38) return FDN_ERR_UNSUPPORTED;                          // (the C = 32 tail is compiled for the stock E = int(1.2 C) = 38: no channel-range predicates)
+    if ((C == 32 && E != 38) || (C == 64 && E != 76)) return FDN_ERR_UNSUPPORTED;                          // (the C = 32 tail is compiled for the stock E = int(1.2 C) = 38: no channel-range predicates)
     if (form == 2 && !fdn_matrix_pipe_wide()) return FDN_ERR_UNSUPPORTED;       // fdn_set_matrix_pipe(2): the level-2 tail keeps its fp32-MFMA form (fdn_fdsa_out)
     FDN_CHECK_ARG((Hd == 0) == (h_out == nullptr) && (reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
     if (Hd > 0 && !fdsa_tail_pin_ok(form, C, Hd)) return FDN_ERR_UNSUPPORTED;
