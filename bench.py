@@ -653,6 +653,7 @@ def main():
                     "fdn_fdsa_fused + fdn_fdsa_out (DESIGN.md section 4: built, correct, not the default)")
     ap.add_argument("--fdsa-pair", action="store_true", help="A/B: the FDSA sub-blocks of levels 1-2 as fdn_fdsa_fused + fdn_fdsa_out (two launches, the 4E-plane hand-off "
                     "through HBM: the round-5 route) instead of fdn_fdsa_fused_tail")
+    ap.add_argument("--tail-pin-l2", action="store_true", help="A/B: the level-2 FDFFN project_in (64 -> 172) inside fdn_fdsa_fused_tail as well (default: level 1 only; measured slower at step level)")
     ap.add_argument("--no-tail-pin", action="store_true", help="A/B: the FDFFN project_in of level 1 as its own fdn_conv1x1 launch instead of inside fdn_fdsa_fused_tail")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short side measurements of BASELINE.json configs[2] (1080p B = 4 bf16 storage) "
                     "and configs[4] (LPNet alone) that the default headline run appends as `other_configs`")
@@ -720,6 +721,7 @@ def main():
         fdn_hip.ops.FDSA_FULL = bool(a.fdsa_full)
         fdn_hip.ops.FDSA_TAIL = not a.fdsa_pair
         fdn_hip.ops.FDSA_TAIL_PIN = not a.no_tail_pin
+        fdn_hip.ops.FDSA_TAIL_PIN_MAX_C = 64 if a.tail_pin_l2 else 32
         if a.narrow_pipe:
             fdn_hip.set_matrix_pipe("bf16-narrow")
         fdn_hip.ops.SPECTRAL_MLP_FUSED = not a.unfused_mlps
@@ -814,7 +816,7 @@ def main():
             and (a.height, a.width) == (720, 1280) and not a.no_parity):
         parity = parity_against_reference(forward, x)
 
-    default_routing = not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
+    default_routing = not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.tail_pin_l2 or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)
 
     def roofline_of(xin, dtype, hw, lpnet_only=False):
         """(roofline of the dominant individual kernel, top 3, the matching committed PMC profile or None) from two instrumented single-stream
@@ -882,7 +884,7 @@ def main():
     # graph, untimed warm-up, K steps between synchronisations), so that every run of the headline command records them too (VERDICT r4, row g)
     other = None
     if (rank == 0 and world == 1 and not a.dry_run and not a.no_other_configs and a.config == "fdn" and a.variant == "lolblur" and a.graph
-            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
+            and a.dtype == "f32" and (a.height, a.width, a.batch) == (720, 1280, 8) and not (a.fdsa_full or a.fdsa_pair or a.no_tail_pin or a.tail_pin_l2 or a.narrow_pipe or a.unfused_mlps or a.stats_launches or a.resample_upsample or a.aff_resized)):
         from fdn_hip.pipeline import GraphedStep
 
         def side(fn, xin, steps=3):
@@ -957,7 +959,7 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"batch-shard x{world}",
                        "weights": "synthetic (tamed 0.03) FDN + real LPNet", "scatter_gather_timed": bool(sg), "hip_streams": a.streams,
-                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "fdsa_pair": bool(a.fdsa_pair), "no_tail_pin": bool(a.no_tail_pin), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
+                       "rccl_ranks": dist.get_world_size() if dist is not None else 1, "hip_graph": bool(a.graph), "fdsa_full": bool(a.fdsa_full), "fdsa_pair": bool(a.fdsa_pair), "no_tail_pin": bool(a.no_tail_pin), "tail_pin_l2": bool(a.tail_pin_l2), "narrow_pipe": bool(a.narrow_pipe), "unfused_mlps": bool(a.unfused_mlps), "stats_launches": bool(a.stats_launches), "resample_upsample": bool(a.resample_upsample), "aff_resized": bool(a.aff_resized),
                        "host_issue_ms_per_step": host_issue_ms, "cpu_affinity_rank0": affinity},
             "whole_path": whole_path_of(a.dtype, P, B, ips / world, dt / a.steps, prof if a.config != "lpnet" else None),
             "roofline": roof, "top_kernels": top, "cpu_baseline": cpu, "other_configs": other,

@@ -106,7 +106,7 @@ class FDSA(nn.Module):
                 # (round 6) one launch: the workgroup that produced a tile's (out1|out2|out3|v_value) planes runs the tail on them itself
                 tsrc = [self.project_out.weight] + [n.body.weight for n in norms] + [n.body.bias for n in norms]
                 img, hd = None, 0
-                if pin is not None and ops.FDSA_TAIL_PIN and res is not None and fdn_hip.storage_dtype() == "f32":      # (bf16 mode stores h as bf16: fdn_conv1x1)
+                if pin is not None and ops.FDSA_TAIL_PIN and x.shape[1] <= ops.FDSA_TAIL_PIN_MAX_C and res is not None and fdn_hip.storage_dtype() == "f32":      # (bf16 mode stores h as bf16: fdn_conv1x1)
                     pw = pin[0].project_in.weight
                     img = self._c.get("tlp", tsrc + [pw, pin[1][0], pin[1][1]], lambda: ops.fdsa_tail_pack(
                         _w(self.project_out.weight), gam, bet, x.shape[1], pin=ops.fold_ln(_w(pw), None, pin[1][0], pin[1][1])))

@@ -44,6 +44,7 @@ __device__ __forceinline__ T tl_sq_acc(T q, T dl, bool live) {
 // padded to whole KB (one LDS-DMA wave instruction moves 64 lanes x 16 bytes)
 __host__ __device__ constexpr int tl_image_floats(int SH, int MT) { return ((6 * 2 * SH + 3 * 2 * SH * (MT * 32 + 1) + 255) / 256) * 256; }
 
+__host__ __device__ constexpr int tl_image_floats_px1_c(int SH, int MT) { return 512 + 3 * ((SH + 7) / 8) * MT * 3 * 64 * 4; }      // level-2 image without project_in
 struct TailIo {
     const float* scr;        // this tile's planes: [4E][256] floats (pixel = 32 row + col)
     const float* res;        // image base [N][P] or null
@@ -266,7 +267,9 @@ __device__ __forceinline__ Tp* tl_uniform_ptr(Tp* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<Tp*>(((unsigned long long)hi << 32) | lo);
 }
-template <int SH, int MT, bool FULL = false>          // FULL: E == 2 SH and N == 32 MT (the stock level 2: E = 76, C = 64): no channel-range predicates
+// PIN (C = 64 only): the following FDFFN's project_in (64 -> Hd <= 32 NT) as gemm_split_strip_kernel<4, FDN_PRO_LN> computes it - see fdsa_tail_px2; its
+// packed operands ([NT][4 k-steps][3 parts][64 lanes] x 16 bytes, then 32 NT bias floats) are read from the image in global memory (72 KB: L1 / L2 hits)
+template <int SH, int MT, bool FULL = false, bool PIN = false, int NT = 6>          // FULL: E == 2 SH and N == 32 MT (the stock level 2: E = 76, C = 64): no channel-range predicates
 __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb, lds_cu4 W0, lds_cu4 W1, const float* gimg_,
                                               unsigned long long* trc = nullptr) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -274,7 +277,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
     io.scr = tl_uniform_ptr(io_.scr); io.res = tl_uniform_ptr(io_.res); io.y = tl_uniform_ptr(io_.y); io.stats_out = tl_uniform_ptr(io_.stats_out);
     io.E = __builtin_amdgcn_readfirstlane(io_.E); io.N = __builtin_amdgcn_readfirstlane(io_.N); io.W = __builtin_amdgcn_readfirstlane(io_.W);
     io.ty0 = __builtin_amdgcn_readfirstlane(io_.ty0); io.tx0 = __builtin_amdgcn_readfirstlane(io_.tx0); io.P = __builtin_amdgcn_readfirstlane(io_.P);
-    io.h = nullptr; io.Hd = 0; io.ring_flag = tl_uniform_ptr(io_.ring_flag); io.ring_cnt = io_.ring_cnt;
+    io.h = tl_uniform_ptr(io_.h); io.Hd = __builtin_amdgcn_readfirstlane(io_.Hd); io.ring_flag = tl_uniform_ptr(io_.ring_flag); io.ring_cnt = io_.ring_cnt;
     const float* gimg = tl_uniform_ptr(gimg_);
     constexpr int E2 = 2 * SH, NQ = (SH + 7) / 8;
     const int E = io.E, N = io.N;
@@ -409,7 +412,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
                 outv[mt][r] = (FULL || nrow + 4 * khl < N) ? o : 0.f;
                 sm += outv[mt][r];
             }
-        if (io.stats_out) {
+        if (io.stats_out || PIN) {
             float sq = 0.f;
             const float mean = tl_xsum32(sm) / (float)N;
 #pragma unroll
@@ -420,16 +423,73 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
                     sq = tl_sq_acc<FULL>(sq, dl, mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khl < N);
                 }
             const float rstd = tl_rsqrt_eps(tl_xsum32(sq) / (float)N);
-            if (kh == 0) {
+            if (io.stats_out && kh == 0) {
                 const trsrc_t rs_ = tl_rsrc(io.stats_out, 2u * P4);
                 const unsigned vs = ok ? pix * 4u : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mean), rs_, vs, 0u, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstd), rs_, vs, P4, 0);
             }
+            if constexpr (PIN) {
+                static_assert(MT == 2, "project_in behind the level-2 tail: K = 64");
+                const float sa = rstd, sb = -mean * sa;                                   // gemm_split: v = fmaf(v, rstd, -mean * rstd)
+                fdn_u32x4 Bf[4][3];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int mt = ks >> 1, h8 = 8 * (ks & 1);
+                    float v[8];
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fmaf(outv[mt][h8 + b4], sa, sb)), __float_as_uint(fmaf(outv[mt][h8 + 4 + b4], sa, sb)), false, false);
+                        v[b4] = __uint_as_float(sw[0]);
+                        v[4 + b4] = __uint_as_float(sw[1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned p1, p2, p3;
+                        fdn_split3(v[2 * j], v[2 * j + 1], p1, p2, p3);
+                        Bf[ks][0][j] = p1, Bf[ks][1][j] = p2, Bf[ks][2][j] = p3;
+                    }
+                }
+                const trsrc_t rpw = tl_rsrc(gimg + tl_image_floats_px1_c(SH, MT), (unsigned)(NT * 4 * 3 * 64 * 16 + NT * 32 * 4));
+                const trsrc_t rh = tl_rsrc(io.h, (unsigned)io.Hd * P4);
+                const unsigned vh = ok ? (4u * kh * P + pix) * 4u : 0x80000000u;
+                auto aload = [&](int t, int ks, fdn_u32x4 (&a3)[3]) {
+#pragma unroll
+                    for (int part = 0; part < 3; ++part)
+                        a3[part] = __builtin_amdgcn_raw_buffer_load_b128(rpw, (unsigned)lane * 16u, (unsigned)(((t * 4 + ks) * 3 + part) * 1024), 0);
+                };
+                // the operands of tile t + 1 and its bias are requested in front of tile t's MFMAs (two register sets): read on the spot they cost an
+                // exposed L2 round trip per tile and the fused project_in was no faster than its own launch
+                fdn_u32x4 a3[2][4][3], bv[2][4];
+                auto tload = [&](int t, int bufi) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) aload(t, ks, a3[bufi][ks]);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        bv[bufi][g4] = __builtin_amdgcn_raw_buffer_load_b128(rpw, (unsigned)(8 * g4 + 4 * kh) * 4u, (unsigned)(NT * 4 * 3 * 1024 + t * 128), 0);
+                };
+                tload(0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (t + 1 < NT) tload(t + 1, (t + 1) & 1);
+                    f32x16 ah;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const fdn_u32x4 b_ = bv[t & 1][g4];
+                        ah[4 * g4] = __uint_as_float(b_.x), ah[4 * g4 + 1] = __uint_as_float(b_.y), ah[4 * g4 + 2] = __uint_as_float(b_.z), ah[4 * g4 + 3] = __uint_as_float(b_.w);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) ah = fdn_mfma_split6(a3[t & 1][ks], Bf[ks], ah);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)                        // rows >= Hd fall outside the descriptor
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ah[r]), rh, vh, (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * P4l, 0);
+                }
+            }
         }
     }
     TLTR(6)
 }
+__host__ __device__ constexpr int tl_pin_floats_l2(int NT) { return NT * 4 * 3 * 64 * 4 + 256; }     // level 2: four k-steps
 __host__ __device__ constexpr int tl_pin_floats(int NT) { return NT * 2 * 3 * 64 * 4 + 256; }        // A operands + one KB of bias
 __host__ __device__ constexpr int tl_image_floats_px1(int SH, int MT) { return 512 + 3 * ((SH + 7) / 8) * MT * 3 * 64 * 4; }
 

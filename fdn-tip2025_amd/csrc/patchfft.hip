@@ -1173,10 +1173,11 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         fdsa_tail_px2<SH, PIN, 3, FULL>(io, hid, hid + NBLK0 * 256);
 #endif
     }
-    if constexpr (TAIL == 2) {
+    if constexpr (TAIL == 2 || TAIL == 4) {
         // ---- level 2 (fdsa_tail_px1): gamma -> wks, beta -> fgs, group 0's packed operands -> hid (all dead behind the last chunk's third barrier);
         // group 1's -> S, which the last inverse rows still read: behind the barrier
         constexpr int SH = 38, MT = 2, NQ = (SH + 7) / 8, GB = NQ * MT * 3;           // GB: KB (= wave-level DMA instructions) per group
+        constexpr bool PIN2 = TAIL == 4;            // + the next sub-block's project_in (64 -> Hd), operands behind the tail's own image, read from global
         const rsrc_t rtw = mk_rsrc(a.tw, (unsigned)tl_image_floats_px1(SH, MT) * 4u);
         auto dma = [&](const void* dst, int src_blk, int nblk, int first = -1) {          // waves take the KB blocks in turn (first: starting wave)
             for (int i = first < 0 ? wave : (wave - first) & 3; i < nblk; i += 4) {
@@ -1206,13 +1207,14 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         io.y = a.y + (long)b * a.N * P;
         io.stats_out = a.stats_out ? a.stats_out + (long)b * 2 * P : nullptr;
         io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
-        io.h = nullptr; io.Hd = 0;
+        io.h = PIN2 ? a.h + (long)b * a.Hd * P : nullptr;
+        io.Hd = a.Hd;
         io.ring_flag = FDN_RING ? reinterpret_cast<unsigned*>(a.out) + ring_s[0] : nullptr;
         io.ring_cnt = ring_s + 1;
 #ifdef FDN_FUSED_TRACE
-        fdsa_tail_px1<SH, MT, C == 64>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw, trc);
+        fdsa_tail_px1<SH, MT, C == 64, PIN2>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw, trc);
 #else
-        fdsa_tail_px1<SH, MT, C == 64>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw);      // (C = 64 is always the stock E = 76: checked by the launcher)
+        fdsa_tail_px1<SH, MT, C == 64, PIN2>(io, (lds_cf)wks, (lds_cf)fgs, (lds_cu4)hid, (lds_cu4)S, a.tw);      // (C = 64 is always the stock E = 76: checked by the launcher)
 #endif
     }
 }
@@ -1397,11 +1399,11 @@ extern "C" int fdn_fdsa_fused(const float* x, long xbs, const float* stats, cons
 
 // project_in's operands behind the level-1 image (fdsa_tail_px2<.., PIN>): [NT][2 k-steps][3 parts][64 lanes] 16-byte A operands of the LayerNorm-folded
 // weights wf [Hd][C] - lane (n, kh) holds the part-th bf16 part of wf[32 t + n][16 ks + 8 kh + 0..7] - then NT * 32 folded bias values, padded to one KB
-static __global__ void fdsa_tail_pack_pin_kernel(const float* __restrict__ wf, const float* __restrict__ bf, float* __restrict__ img, int C, int Hd, int NT) {
+static __global__ void fdsa_tail_pack_pin_kernel(const float* __restrict__ wf, const float* __restrict__ bf, float* __restrict__ img, int C, int Hd, int NT, int NKS) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nop = NT * 2 * 3 * 64;
+    const int nop = NT * NKS * 3 * 64;
     if (i < nop) {
-        const int l = i & 63, part = (i >> 6) % 3, ks = (i / 192) & 1, t = i / 384;
+        const int l = i & 63, part = (i >> 6) % 3, ks = (i / 192) % NKS, t = i / (192 * NKS);
         const int n = t * 32 + (l & 31), kh = l >> 5;
         fdn_u32x4 o;
 #pragma unroll
@@ -1461,12 +1463,14 @@ static int fdsa_tail_form(int C, int E, int N, int* sh, int* mt) {      // 0 = n
     if ((C == 48 || C == 64) && E > 38 && E <= 76 && N > 32 && N <= 64) { *sh = 38; *mt = 2; return 2; }
     return 0;
 }
-static bool fdsa_tail_pin_ok(int form, int C, int Hd) { return form == 1 && Hd > 0 && Hd <= 96 && 2 * Hd >= 5 * C; }      // fdn_conv1x1's strip<2> shapes
+static bool fdsa_tail_pin_ok(int form, int C, int Hd) {      // fdn_conv1x1's strip<2> shapes at level 1, strip<4> at C = 64
+    return Hd > 0 && 2 * Hd >= 5 * C && ((form == 1 && Hd <= 96) || (form == 2 && C == 64 && Hd <= 192));
+}
 extern "C" long fdn_fdsa_tail_pack_floats(int C, int E, int N, int Hd) {
     int sh, mt;
     const int form = fdsa_tail_form(C, E, N, &sh, &mt);
     if (Hd > 0 && !fdsa_tail_pin_ok(form, C, Hd)) return 0;
-    return form == 1 ? tl_image_floats(sh, mt) + (Hd > 0 ? tl_pin_floats(3) : 0) : form == 2 ? tl_image_floats_px1(sh, mt) : 0;
+    return form == 1 ? tl_image_floats(sh, mt) + (Hd > 0 ? tl_pin_floats(3) : 0) : form == 2 ? tl_image_floats_px1(sh, mt) + (Hd > 0 ? tl_pin_floats_l2(6) : 0) : 0;
 }
 extern "C" long fdn_fdsa_scratch_floats(int B, int E, int H, int W) {
     if (B <= 0 || E <= 0 || H <= 0 || W <= 0 || H % 8) return 0;
@@ -1483,12 +1487,14 @@ extern "C" int fdn_fdsa_tail_pack(const float* w, const float* gamma3, const flo
     if (form == 2) {
         const int nthreads = 512 + (tl_image_floats_px1(sh, mt) - 512) / 4;     // 512 header floats + one thread per 16-byte operand
         hipLaunchKernelGGL(fdsa_tail_pack_px1_kernel, dim3(cdiv(nthreads, 256)), dim3(256), 0, s, w, gamma3, beta3, img, E, N, sh, mt);
+        if (Hd > 0)
+            hipLaunchKernelGGL(fdsa_tail_pack_pin_kernel, dim3(cdiv(6 * 4 * 3 * 64 + 256, 256)), dim3(256), 0, s, pin_w, pin_b, img + tl_image_floats_px1(sh, mt), C, Hd, 6, 4);
         return fdn_launch_status();
     }
     const int total = tl_image_floats(sh, mt);
     hipLaunchKernelGGL(fdsa_tail_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, gamma3, beta3, img, E, N, sh, mt, total);
     if (Hd > 0)
-        hipLaunchKernelGGL(fdsa_tail_pack_pin_kernel, dim3(cdiv(3 * 2 * 3 * 64 + 256, 256)), dim3(256), 0, s, pin_w, pin_b, img + total, C, Hd, 3);
+        hipLaunchKernelGGL(fdsa_tail_pack_pin_kernel, dim3(cdiv(3 * 2 * 3 * 64 + 256, 256)), dim3(256), 0, s, pin_w, pin_b, img + total, C, Hd, 3, 2);
     return fdn_launch_status();
 }
 extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
@@ -1528,7 +1534,13 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
         break;
     switch (C) {
         FDN_FUSED_TAIL_CASE(48, 2)
-        FDN_FUSED_TAIL_CASE(64, 2)
+        case 64:
+            if (Hd > 0) {
+                switch (C) { FDN_FUSED_TAIL_CASE(64, 4) }
+            } else {
+                switch (C) { FDN_FUSED_TAIL_CASE(64, 2) }
+            }
+            break;
         case 24:
         case 32:
             if (Hd > 0) {

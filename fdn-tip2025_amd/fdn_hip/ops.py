@@ -315,6 +315,8 @@ def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=F
     return out
 
 
+FDSA_TAIL_PIN_MAX_C = 32    # widths up to which the following FDFFN's project_in rides in the FDSA launch.  64 (level 2 too: the kernel exists, bit-identical) measured
+                            # 278.75 against 277.66 ms per step (three alternating runs, profiles/r06_h_bench_*.json): the 72 KB of operands come from L2 per tile
 FDSA_TAIL_PIN = True        # (round 6) level 1: that launch also runs the following FDFFN's project_in (bit-identical to fdn_conv1x1's kernel for the shape)
 FDSA_FULL = False           # True: the whole FDSA sub-block in one launch (fdn_fdsa_full) for C <= FDSA_FULL_MAX_C; False: fdn_fdsa_fused + fdn_fdsa_out
 FDSA_FULL_MAX_C = 32        # measured (tools/ab_fdsa_full.py, B = 8 720p shapes): one launch 3.52 against 3.77 ms at C = 32 and 2.89 against 2.93 at

@@ -78,7 +78,7 @@ def weights_signature(*modules):
     change of ops.FDSA_FULL the key differs and the holder captures again."""
     from . import matrix_pipe_mode, ops
     ps = [p for m in modules for p in list(m.parameters()) + list(m.buffers())]
-    return (storage_dtype(), matrix_pipe_mode(), bool(ops.FDSA_FULL), int(ops.FDSA_FULL_MAX_C), bool(ops.FDSA_TAIL), bool(ops.FDSA_TAIL_PIN), str(ops.FFN_TAIL_MODE), bool(ops.SPECTRAL_MLP_FUSED), bool(ops.GEMM_OWN_STATS), bool(ops.UPCONV_GATHER), bool(ops.AFF_MULTIRES),
+    return (storage_dtype(), matrix_pipe_mode(), bool(ops.FDSA_FULL), int(ops.FDSA_FULL_MAX_C), bool(ops.FDSA_TAIL), bool(ops.FDSA_TAIL_PIN), int(ops.FDSA_TAIL_PIN_MAX_C), str(ops.FFN_TAIL_MODE), bool(ops.SPECTRAL_MLP_FUSED), bool(ops.GEMM_OWN_STATS), bool(ops.UPCONV_GATHER), bool(ops.AFF_MULTIRES),
             len(ps), sum(p._version for p in ps), sum(p.data_ptr() & 0xFFFFFFFF for p in ps))
 
 
