@@ -106,7 +106,8 @@ class FDSA(nn.Module):
                 # (round 6) one launch: the workgroup that produced a tile's (out1|out2|out3|v_value) planes runs the tail on them itself
                 tsrc = [self.project_out.weight] + [n.body.weight for n in norms] + [n.body.bias for n in norms]
                 img, hd = None, 0
-                if pin is not None and ops.FDSA_TAIL_PIN and x.shape[1] <= ops.FDSA_TAIL_PIN_MAX_C and res is not None and fdn_hip.storage_dtype() == "f32":      # (bf16 mode stores h as bf16: fdn_conv1x1)
+                hst = ops.block_storage(x.shape[1], x.shape[2] * x.shape[3], hidden=pin[0].project_in.weight.shape[0]) if pin is not None else torch.float32
+                if pin is not None and ops.FDSA_TAIL_PIN and x.shape[1] <= ops.FDSA_TAIL_PIN_MAX_C and res is not None and (hst == torch.float32 or x.shape[1] <= 32):
                     pw = pin[0].project_in.weight
                     img = self._c.get("tlp", tsrc + [pw, pin[1][0], pin[1][1]], lambda: ops.fdsa_tail_pack(
                         _w(self.project_out.weight), gam, bet, x.shape[1], pin=ops.fold_ln(_w(pw), None, pin[1][0], pin[1][1])))
@@ -115,7 +116,7 @@ class FDSA(nn.Module):
                     img = self._c.get("tl", tsrc, lambda: ops.fdsa_tail_pack(_w(self.project_out.weight), gam, bet, x.shape[1]))
                 if img is not None:
                     y = ops.fdsa_fused_tail(x, ln[0] if ln is not None else None, wpk, _w(self.to_hidden_dw.weight), _w(self.fft), img,
-                                            res=res, want_stats=res is not None, Hd=hd)
+                                            res=res, want_stats=res is not None, Hd=hd, h_dtype=hst if hd else torch.float32)
                     if y is not None:
                         return y
             o = ops.fdsa_fused(x, ln[0] if ln is not None else None, wpk, _w(self.to_hidden_dw.weight), _w(self.fft),

@@ -54,6 +54,7 @@ struct TailIo {
     unsigned P;
     float* h;                // PIN: image base [Hd][P] of the NEXT sub-block's project_in output (FDFFN, FDN_arch.py:456), Hd rows
     int Hd;
+    int h_bf16;              // PIN: h is stored as bf16 (bf16-storage mode: round-to-nearest-even of the fp32 result, two pixels per dword)
     unsigned* ring_flag;     // ring mode: this workgroup's slot flag (given back when the last wave's read-back has landed) or null
     int* ring_cnt;           // LDS counter of waves whose read-back has landed
 };
@@ -234,10 +235,18 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
                     ah[0] = fdn_mfma_split6(a3, Bf[0][ks], ah[0]);
                     ah[1] = fdn_mfma_split6(a3, Bf[1][ks], ah[1]);
                 }
+                if (io.h_bf16) {                                        // (uniform) bf16 storage: the pixel pair is one dword
+                    const trsrc_t rhb = tl_rsrc(io.h, (unsigned)io.Hd * P * 2u);
+                    const unsigned vhb = ok ? (4u * kh * P + pix) * 2u : 0x80000000u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)                            // rows >= Hd fall outside the descriptor
-                    __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(ah[0][r]), __float_as_uint(ah[1][r])}, rh, vh,
-                                                          (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * P4, 0);
+                    for (int r = 0; r < 16; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(pack_bf16(ah[0][r], ah[1][r]), rhb, vhb, (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * P * 2u, 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)                        // rows >= Hd fall outside the descriptor
+                        __builtin_amdgcn_raw_buffer_store_b64(fdn_u32x2{__float_as_uint(ah[0][r]), __float_as_uint(ah[1][r])}, rh, vh,
+                                                              (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * P4, 0);
+                }
             }
         }
     }
@@ -277,7 +286,7 @@ __device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb
     io.scr = tl_uniform_ptr(io_.scr); io.res = tl_uniform_ptr(io_.res); io.y = tl_uniform_ptr(io_.y); io.stats_out = tl_uniform_ptr(io_.stats_out);
     io.E = __builtin_amdgcn_readfirstlane(io_.E); io.N = __builtin_amdgcn_readfirstlane(io_.N); io.W = __builtin_amdgcn_readfirstlane(io_.W);
     io.ty0 = __builtin_amdgcn_readfirstlane(io_.ty0); io.tx0 = __builtin_amdgcn_readfirstlane(io_.tx0); io.P = __builtin_amdgcn_readfirstlane(io_.P);
-    io.h = tl_uniform_ptr(io_.h); io.Hd = __builtin_amdgcn_readfirstlane(io_.Hd); io.ring_flag = tl_uniform_ptr(io_.ring_flag); io.ring_cnt = io_.ring_cnt;
+    io.h = tl_uniform_ptr(io_.h); io.Hd = __builtin_amdgcn_readfirstlane(io_.Hd); io.h_bf16 = 0; io.ring_flag = tl_uniform_ptr(io_.ring_flag); io.ring_cnt = io_.ring_cnt;
     const float* gimg = tl_uniform_ptr(gimg_);
     constexpr int E2 = 2 * SH, NQ = (SH + 7) / 8;
     const int E = io.E, N = io.N;

@@ -672,8 +672,8 @@ struct FusedArgs {
     float* y;
     float* stats_out;
     int N;
-    float* h;            // TAIL 3: the following FDFFN's project_in output [B][Hd][H][W]
-    int Hd;
+    float* h;            // TAIL 3: the following FDFFN's project_in output [B][Hd][H][W] (h_bf16: stored as bf16)
+    int Hd, h_bf16;
 };
 #ifndef FDN_RING
 #define FDN_RING 1          // TAIL kernels: 1 = `out` is a RING of per-(CU, resident workgroup) blocks behind FDN_RING_SLOTS flag words (0 = free); 0 = one block per tile (A/B builds)
@@ -1161,8 +1161,9 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         io.y = a.y + (long)b * a.N * P;
         io.stats_out = a.stats_out ? a.stats_out + (long)b * 2 * P : nullptr;
         io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
-        io.h = PIN ? a.h + (long)b * a.Hd * P : nullptr;
+        io.h = PIN ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.h) + (long)b * a.Hd * P * (a.h_bf16 ? 2 : 4)) : nullptr;
         io.Hd = a.Hd;
+        io.h_bf16 = a.h_bf16;
         io.ring_flag = FDN_RING ? reinterpret_cast<unsigned*>(a.out) + ring_s[0] : nullptr;
         io.ring_cnt = ring_s + 1;
         // (C = 32 is always the stock E = 38, N = 32: fdn_fdsa_fused_tail checks it; C = 24 keeps the channel-range predicates)
@@ -1209,6 +1210,7 @@ __global__ __launch_bounds__(256, FDN_FUSED_WGS) void fdsa_fused_kernel(FusedArg
         io.E = E; io.N = a.N; io.W = W; io.ty0 = ty0; io.tx0 = tx0; io.P = P;
         io.h = PIN2 ? a.h + (long)b * a.Hd * P : nullptr;
         io.Hd = a.Hd;
+        io.h_bf16 = 0;
         io.ring_flag = FDN_RING ? reinterpret_cast<unsigned*>(a.out) + ring_s[0] : nullptr;
         io.ring_cnt = ring_s + 1;
 #ifdef FDN_FUSED_TRACE
@@ -1498,8 +1500,9 @@ extern "C" int fdn_fdsa_tail_pack(const float* w, const float* gamma3, const flo
     return fdn_launch_status();
 }
 extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
-                                   const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, float* h_out, int B,
-                                   int C, int E, int H, int W, int Hd, fdn_stream_t stream) {
+                                   const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, void* h_out_, int B,
+                                   int C, int E, int H, int W, int Hd, int h_bf16, fdn_stream_t stream) {
+    float* h_out = static_cast<float*>(h_out_);
     FDN_CHECK_ARG(x && wpk && dw_w && fft_w && tail_img && out && scratch && B > 0 && E > 0 && H > 0 && W > 0);
     FDN_CHECK_ARG(H % 8 == 0 && W % 8 == 0);
     FDN_CHECK_ARG(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(stats_out) |
@@ -1514,6 +1517,7 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     if (form == 2 && !fdn_matrix_pipe_wide()) return FDN_ERR_UNSUPPORTED;       // fdn_set_matrix_pipe(2): the level-2 tail keeps its fp32-MFMA form (fdn_fdsa_out)
     FDN_CHECK_ARG((Hd == 0) == (h_out == nullptr) && (reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
     if (Hd > 0 && !fdsa_tail_pin_ok(form, C, Hd)) return FDN_ERR_UNSUPPORTED;
+    if (h_bf16 && (form != 1 || Hd <= 0)) return FDN_ERR_UNSUPPORTED;           // bf16 h: the level-1 form only
     FDN_CHECK_ARG(4ull * (Hd + 40) * H * W < 0x80000000ull);
     FusedArgs a;
     a.x = x; a.xbs = xbs; a.stats = stats; a.wpk = wpk; a.dww = dw_w; a.fftw = fft_w; a.out = scratch;
@@ -1522,7 +1526,7 @@ extern "C" int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats,
     a.tiles_per_img = a.tiles_x * (H / FT_H);
     a.nchunks = (E + FEG - 1) / FEG;
     a.tw = tail_img; a.res = res; a.y = out; a.stats_out = stats_out; a.N = C;
-    a.h = h_out; a.Hd = Hd;
+    a.h = h_out; a.Hd = Hd; a.h_bf16 = h_bf16;
     const long total = (long)B * a.tiles_per_img;
     FDN_CHECK_ARG(total < 0x7fffffffL);
     const dim3 grid((unsigned)total), block(256);

@@ -287,7 +287,7 @@ def fdsa_tail_pack(w_out, gamma3, beta3, C, pin=None):
     return img
 
 
-def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=False, Hd=0):
+def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=False, Hd=0, h_dtype=torch.float32):
     """x [B,C,H,W] -> res + project_out(norm1..3(FDSA core(LN(x))) * v_value) in ONE launch (fdn_fdsa_fused_tail), bit-identical to
     fdsa_fused + fdsa_out.  Hd > 0 (tail_img packed with `pin`): also h = project_in(LN(out)) [B,Hd,H,W] of the FDFFN that follows, attached to
     the result as `._fdn_pin`.  Returns None when the library has no form for the shape."""
@@ -301,10 +301,10 @@ def fdsa_fused_tail(x, stats, wpk, dw_w, fft_w, tail_img, res=None, want_stats=F
         scr = _fdsa_scratch[key] = torch.zeros(n, device=x.device, dtype=torch.float32)
     out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
     st = torch.empty((B, 1, 2, H * W), device=x.device, dtype=torch.float32) if want_stats else None
-    h = torch.empty((B, Hd, H, W), device=x.device, dtype=torch.float32) if Hd else None
+    h = torch.empty((B, Hd, H, W), device=x.device, dtype=h_dtype) if Hd else None
     rc = lib().fdn_fdsa_fused_tail(ptr, ctypes.c_long(xbs), _flat(stats, "stats"), _flat(wpk, "wpk"), _flat(dw_w, "dw_w"), _flat(fft_w, "fft_w"),
                                    _flat(tail_img, "tail_img"), _flat(res, "res"), _flat(out, "out"), _flat(st, "stats_out"), _flat(scr, "scratch"),
-                                   _flat(h, "h_out"), B, C, E, H, W, Hd, stream())
+                                   _flat(h, "h_out", True), B, C, E, H, W, Hd, int(h_dtype == BF16), stream())
     if rc == ERR_UNSUPPORTED:
         return None
     check(rc, "fdn_fdsa_fused_tail")

@@ -171,14 +171,14 @@ int fdn_fdsa_full(const float* x, long xbs, const float* stats, const void* wpk,
  * Hd > 0 (level 1 only: C <= 32, Hd <= 96, 2 Hd >= 5 C): the tail also runs the project_in of the FDFFN that follows the FDSA (FDN_arch.py:456 behind
  *   the LayerNorm of :673) on the values and statistics it holds in registers - h_out [B][Hd][H][W] = pin_w' LN(out) + pin_b', bit for bit what
  *   fdn_conv1x1(FDN_PRO_LN) returns for these operands; pin_w [Hd][C] / pin_b [Hd] are the LayerNorm-FOLDED weights (w diag(gamma), w beta) given to
- *   fdn_fdsa_tail_pack.  Hd = 0: pin_w = pin_b = h_out = NULL. */
+ *   fdn_fdsa_tail_pack.  Hd = 0: pin_w = pin_b = h_out = NULL.  h_bf16 (level 1 only): h_out is stored as bf16 - round-to-nearest-even of the same fp32 result. */
 long fdn_fdsa_tail_pack_floats(int C, int E, int N, int Hd);
 long fdn_fdsa_scratch_floats(int B, int E, int H, int W);
 int fdn_fdsa_tail_pack(const float* w_out, const float* gamma3, const float* beta3, const float* pin_w, const float* pin_b, float* img, int C, int E,
                        int N, int Hd, fdn_stream_t stream);
 int fdn_fdsa_fused_tail(const float* x, long xbs, const float* stats, const float* wpk, const float* dw_w, const float* fft_w,
-                        const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, float* h_out, int B, int C,
-                        int E, int H, int W, int Hd, fdn_stream_t stream);
+                        const float* tail_img, const float* res, float* out, float* stats_out, float* scratch, void* h_out, int B, int C,
+                        int E, int H, int W, int Hd, int h_bf16, fdn_stream_t stream);
 
 /* FDSA tail in one launch (FDN_arch.py:633-639 and the residual add of :671): norm1/2/3 over the E channels
  * of out1|out2|out3, times v_value, project_out (3E -> N) + res, and (optionally) the channel LayerNorm

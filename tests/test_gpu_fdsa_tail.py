@@ -80,6 +80,18 @@ def test_project_in_inside_the_launch_equals_conv1x1(ops, B, C, H, W):
     assert torch.equal(ha, hb), f"h: max |diff| {(ha - hb).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 40, 96), (1, 24, 16, 48)])
+def test_project_in_stored_as_bf16_is_the_rounded_fp32_result(ops, B, C, H, W):
+    """bf16-storage mode (BASELINE configs[2]): h leaves the launch as bf16 - exactly round-to-nearest-even of the fp32 h of the fp32 mode (storage only)."""
+    d = _case(ops, B, C, H, W, seed=3 * C + W, edge=True)
+    img = ops.fdsa_tail_pack(d["wp"], d["g3"], d["b3"], C, pin=ops.fold_ln(d["wi"], None, d["g2"], d["b2"]))
+    y32 = ops.fdsa_fused_tail(d["x"], d["stats"], d["wpk"], d["dw"], d["fw"], img, res=d["x"], want_stats=True, Hd=d["Hd"])
+    y16 = ops.fdsa_fused_tail(d["x"], d["stats"], d["wpk"], d["dw"], d["fw"], img, res=d["x"], want_stats=True, Hd=d["Hd"], h_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(y32, y16) and y16._fdn_pin.dtype == torch.bfloat16
+    assert torch.equal(y16._fdn_pin, y32._fdn_pin.to(torch.bfloat16))
+
+
 def test_ring_is_shared_and_left_clean(ops):
     """One ring serves every launch of the stream: different shapes and widths in turn, twice each - same results every time - and every launch hands all
     its blocks back (the flag words at the head of the ring are zero again)."""

@@ -51,7 +51,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.fdn_fdsa_core(None, None, None, None, 1, 38, 32, 32, None) == 1
     assert lib.fdn_rfft_rows(None, None, ctypes.c_long(4), 16, ctypes.c_long(0), None) == 1
     # (round 6) the one-launch FDSA route: sizes of its operand image / ring are host arithmetic, a width without a form has none
-    assert lib.fdn_fdsa_fused_tail(None, ctypes.c_long(0), None, None, None, None, None, None, None, None, None, None, 1, 32, 38, 32, 32, 0, None) == 1
+    assert lib.fdn_fdsa_fused_tail(None, ctypes.c_long(0), None, None, None, None, None, None, None, None, None, None, 1, 32, 38, 32, 32, 0, 0, None) == 1
     assert lib.fdn_fdsa_tail_pack_floats(32, 38, 32, 0) == 4096 and lib.fdn_fdsa_tail_pack_floats(32, 38, 32, 86) > 4096
     assert lib.fdn_fdsa_tail_pack_floats(64, 76, 64, 0) == 512 + 3 * 5 * 2 * 3 * 64 * 4 and lib.fdn_fdsa_tail_pack_floats(128, 153, 128, 0) == 0
     assert lib.fdn_fdsa_tail_pack_floats(48, 57, 48, 129) == 0                      # no project_in behind the C = 48 tail
