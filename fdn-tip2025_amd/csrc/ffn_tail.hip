@@ -230,6 +230,59 @@ constexpr unsigned SW_OOB = 0x80000000u;
 // (round 4) The two source planes of a pair live in LDS as ONE plane of (A, B) cells and the taps as (wA, wB) pairs: a window cell is
 // one 8-byte read and both stencils advance in one v_pk_fma_f32 - 36 packed FMAs per pair and lane where there were 72 scalar ones.
 // CODD (odd C: the two channels of a pair read different B planes, FDN_lolv1's 129) keeps a second plane of (A, B1) cells for the odd lanes.
+// epilogue of the sliding-window forms: residual, 128-byte row segments, the next LayerNorm's statistics
+template <int MT, int R>
+__device__ __forceinline__ void ffn_tail_epilogue(const FtArgs& a, f32x16 (&acc)[R][MT], int b, int ty0, int tx0, int r0, int col, int kh) {
+    const int N = a.N, H = a.H, W = a.W;
+    const unsigned P = (unsigned)H * W, hw4 = P * 4u;
+    const int gx = tx0 + col;
+    const unsigned nb4 = (unsigned)N * hw4;
+    const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
+    const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int gy = ty0 + r0 + i;
+        const bool ok = gy < H && gx < W;
+        const unsigned pix = ok ? (unsigned)(gy * W + gx) : 0u;
+        const unsigned vo = ok ? (4u * kh * P + pix) * 4u : SW_OOB;
+        float rres[MT][16];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rres[t][q] = bload(rr, vo, (unsigned)(t * 32 + (q & 3) + 8 * (q >> 2)) * hw4);     // 0 without a residual
+        float sm = 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int nrow = t * 32 + (q & 3) + 8 * (q >> 2);
+                float v = acc[i][t][q] + rres[t][q];
+                bstore(v, ro, vo, (unsigned)nrow * hw4);                              // rows >= N fall outside the descriptor
+                v = (nrow + 4 * kh < N) ? v : 0.f;
+                acc[i][t][q] = v;
+                sm += v;
+            }
+        if (a.stats_out) {
+            sm += __shfl_xor(sm, 32);
+            const float mean = sm / (float)N;
+            float sq = 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float dl = acc[i][t][q] - mean;
+                    sq += (t * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh < N) ? dl * dl : 0.f;
+                }
+            sq += __shfl_xor(sq, 32);
+            if (kh == 0 && ok) {
+                float* sp = a.stats_out + (long)b * 2 * P;
+                sp[pix] = mean;
+                sp[P + pix] = 1.0f / sqrtf(sq / (float)N + 1e-5f);
+            }
+        }
+    }
+}
+
 // (round 6) tools/tail_trace.py: -DFDN_TAILSW_TRACE - every wave of 512 workgroups from the middle of the grid sums the s_memtime clocks it spends in the
 // phases of a pair step (request + taps, window / stencil / GELU / MFMA issue, parking the next pair, barrier) and stamps prologue and epilogue;
 // -DFDN_KOT_GELU / _MFMA / _LOADS / _STENCIL knock a phase out (results are wrong: timing only)
@@ -257,7 +310,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8 && !(IBF && CODD && MT == 2)) ? 2
     __shared__ float wl[2][2][MT * 32];                                     // [buffer][k parity][output channel]: the projection's column pair w[n][2m], w[n][2m + 1]
 
     const int C = a.C, N = a.N, H = a.H, W = a.W;
-    const unsigned P = (unsigned)H * W, hwi = P * IES, hw4 = P * 4u;
+    const unsigned P = (unsigned)H * W, hwi = P * IES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
     const int wy = wave >> 1, wx = wave & 1;
     const int item = (int)xcd_contiguous(blockIdx.x, gridDim.x);
@@ -469,53 +522,7 @@ __global__ __launch_bounds__(256, (R * MT <= 8 && !(IBF && CODD && MT == 2)) ? 2
     const unsigned long long tt_epi = __builtin_amdgcn_s_memtime();
 #endif
 
-    // ---- epilogue: residual, store, next LayerNorm's statistics ----------------------------------------------------------
-    const int gx = tx0 + col;
-    const unsigned nb4 = (unsigned)N * hw4;
-    const rsrc_t ro = mk_rsrc(a.out + (long)b * N * P, nb4);
-    const rsrc_t rr = mk_rsrc(a.res ? a.res + (long)b * N * P : a.out, a.res ? nb4 : 0u);
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int gy = ty0 + r0 + i;
-        const bool ok = gy < H && gx < W;
-        const unsigned pix = ok ? (unsigned)(gy * W + gx) : 0u;
-        const unsigned vo = ok ? (4u * kh * P + pix) * 4u : SW_OOB;
-        float rres[MT][16];
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) rres[t][q] = bload(rr, vo, (unsigned)(t * 32 + (q & 3) + 8 * (q >> 2)) * hw4);     // 0 without a residual
-        float sm = 0.f;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int nrow = t * 32 + (q & 3) + 8 * (q >> 2);
-                float v = acc[i][t][q] + rres[t][q];
-                bstore(v, ro, vo, (unsigned)nrow * hw4);                              // rows >= N fall outside the descriptor
-                v = (nrow + 4 * kh < N) ? v : 0.f;
-                acc[i][t][q] = v;
-                sm += v;
-            }
-        if (a.stats_out) {
-            sm += __shfl_xor(sm, 32);
-            const float mean = sm / (float)N;
-            float sq = 0.f;
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float dl = acc[i][t][q] - mean;
-                    sq += (t * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh < N) ? dl * dl : 0.f;
-                }
-            sq += __shfl_xor(sq, 32);
-            if (kh == 0 && ok) {
-                float* sp = a.stats_out + (long)b * 2 * P;
-                sp[pix] = mean;
-                sp[P + pix] = 1.0f / sqrtf(sq / (float)N + 1e-5f);
-            }
-        }
-    }
+    ffn_tail_epilogue<MT, R>(a, acc, b, ty0, tx0, r0, col, kh);
 #ifdef FDN_TAILSW_TRACE
     {
         const unsigned rel = blockIdx.x - gridDim.x / 2;
@@ -530,11 +537,208 @@ __global__ __launch_bounds__(256, (R * MT <= 8 && !(IBF && CODD && MT == 2)) ? 2
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// (round 6) The sliding-window form with the source planes travelling global -> LDS DIRECTLY (buffer_load_dword ... lds), three pair steps ahead.
+// In the form above a plane crosses the registers: requested two steps ahead, it must have LANDED by the end of the next step to be parked in LDS - the
+// trace (tools/tail_trace.py) shows a quarter of a step spent in that park, most of it waiting - and a third register stage costs the third wave per SIMD.
+// Here a step issues, per wave, the rows of pair m + 3 as 64-lane dword loads whose destination is the row record of LDS buffer (m + 3) % 4: no stage
+// registers, no ds_write, and three steps for the data to arrive.  A row record is [A: 72 floats][B: 72 floats] (odd C: a second B plane), so a window cell
+// is still ONE ds_read2_b32 (offsets 0, 72) and the packed stencil is unchanged.  Only the two edge columns (2 x 10 values per plane) keep a register stage:
+// they sit in the record's padding, where a 64-lane load cannot put them.  Taps and projection column land in LDS the same way (one load per wave).
+// Every wave issues the same number of vector-memory instructions per step (a row / a small block that does not exist goes through a descriptor of zero
+// records into a dummy cell), so "pair m + 1 has landed" is s_waitcnt vmcnt(2 x that number) in front of the step's barrier - exact, and by hand: the
+// compiler cannot see that another wave will read what this one's loads wrote.  Arithmetic and its order are the form above's: bit-identical.  fp32 input only.
+// ------------------------------------------------------------------------------------------------
+// Measured (tools/ab_libs.py, interleaved, against the register-staged form above, profiles/r06_tail_dma_ab.txt): 86 -> 32 1.352 against 1.351 ms, 172 -> 64 @L2
+// 0.858 against 0.879 ms; step level 278.0 against 280.3 ms (two alternating pairs on one box, within the noise).  Three steps of slack bought nothing
+// because nothing was waiting any more: after the load fix the kernel is bound by the ~170 instructions of a pair step (at three waves per SIMD the "park" share
+// of the trace is issue time shared with the other waves, not a wait).  NOT the default: -DFDN_TAIL_DMA=1 selects it for fp32 inputs.
+#ifndef FDN_TAIL_DMA
+#define FDN_TAIL_DMA 0
+#endif
+template <int MT, int R, bool CODD>
+__global__ __launch_bounds__(256, (R * MT <= 8) ? 2 : 1) void ffn_tail_dma_kernel(FtArgs a) {
+    constexpr int HRW = 2 * R + 2;                       // halo rows of the tile
+    constexpr int NP = CODD ? 3 : 2;                     // planes per row record: A, B (, B of the odd channel)
+    constexpr int RS = NP * 72;                          // floats per row record: interior at 4 .. 67, left halo at 3, right halo at 68
+    constexpr int PB = (HRW + 2) * RS;                   // (+ two rows nobody reads: waves 2, 3 have a third row slot (10, 11) that takes their OUT-OF-RANGE load -
+                                                         //  every wave then issues the same loads with no branch or select around any of them)
+    constexpr int SM = 4 * 64;                           // taps (wave 0: 40 used) | projection columns [k parity][output channel] (waves 1 .. MT) | unused
+    constexpr int CNT = 3 * NP + 1;                      // direct-to-LDS loads per wave and step
+    __shared__ __attribute__((aligned(16))) float pl0[PB], pl1[PB], pl2[PB], pl3[PB];
+    __shared__ __attribute__((aligned(16))) float sm0[SM], sm1[SM], sm2[SM], sm3[SM];
+
+    const int C = a.C, N = a.N, H = a.H, W = a.W;
+    const unsigned P = (unsigned)H * W, hw4 = P * 4u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5, ln = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wy = wave >> 1, wx = wave & 1;
+    const int item = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = item / a.tiles_per_img, t_ = item - b * a.tiles_per_img;
+    const int ty0 = (t_ / a.tiles_x) * (2 * R), tx0 = (t_ % a.tiles_x) * SW_TC;
+    const rsrc_t rin = mk_rsrc(a.y + (long)b * C * P, (unsigned)C * hw4);
+    const rsrc_t rdead = mk_rsrc(a.y, 0u);
+    const rsrc_t rdw = mk_rsrc(a.wdw, (unsigned)(2 * C * 9) * 4u), rwp = mk_rsrc(a.w, (unsigned)(N * C) * 4u);
+    const int npairs = (C + 1) / 2;
+
+    // this wave's rows of a record (wave, wave + 4, wave + 8), lane = column
+    unsigned vrow[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int rr = wave + 4 * j, y = ty0 - 1 + rr, x = tx0 + lane;
+        vrow[j] = (rr < HRW && y >= 0 && y < H && x < W) ? (unsigned)(y * W + x) * 4u : SW_OOB;
+    }
+    // the two edge columns: threads 0 .. 2 HRW - 1 (image column tx0 - 1 -> cell 3, tx0 + 64 -> cell 68)
+    unsigned ge;
+    int se;
+    {
+        const int er = tid >> 1, side = tid & 1;
+        const int ey = ty0 - 1 + er, ex = side ? tx0 + SW_TC : tx0 - 1;
+        const bool eok = tid < 2 * HRW && ey >= 0 && ey < H && ex >= 0 && ex < W;
+        ge = eok ? (unsigned)(ey * W + ex) * 4u : SW_OOB;
+        se = tid < 2 * HRW ? er * RS + (side ? 68 : 3) : -1;
+    }
+    // the small block of this wave: wave 0 the 40 taps, waves 1 .. MT the projection's column pair
+    unsigned vsm;
+    int sm_par;
+    {
+        const int par = tid / 20, i = tid - par * 20, tap = i >> 1;
+        sm_par = par;
+        vsm = (tid < 40 && tap < 9) ? (unsigned)((((i & 1) ? C : 0) + par) * 9 + tap) * 4u : SW_OOB;       // + 72 m
+        if (wv >= 1 && wv <= MT) {
+            const int u = tid - 64, n = u % (MT * 32);
+            sm_par = u / (MT * 32);
+            vsm = n < N ? (unsigned)(n * C + sm_par) * 4u : SW_OOB;                                        // + 8 m
+        }
+    }
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    float qe[2][NP];                                     // edge values: two register stages
+    auto fetch_edges = [&](int m, float (&q)[NP]) {
+        const bool live = m < npairs;
+        const rsrc_t ri = live ? rin : rdead;
+        const int j0 = 2 * m, j1 = (2 * m + 1 < C) ? 2 * m + 1 : 2 * m;
+        q[0] = bload(ri, ge, (unsigned)m * hw4);
+        q[1] = bload(ri, ge, (unsigned)((C + j0) >> 1) * hw4);
+        if (CODD) q[NP - 1] = bload(ri, ge, (unsigned)((C + j1) >> 1) * hw4);
+    };
+    auto park_edges = [&](float* pl, const float (&q)[NP]) {
+        if (se >= 0) {
+#pragma unroll
+            for (int p_ = 0; p_ < NP; ++p_) pl[se + 72 * p_] = q[p_];
+        }
+    };
+    auto dma = [&](int m, float* pl, float* smb) {       // CNT loads per wave, whatever m and the wave
+        const bool live = m < npairs;
+        const rsrc_t ri = live ? rin : rdead;
+        const int j0 = 2 * m, j1 = (2 * m + 1 < C) ? 2 * m + 1 : 2 * m;
+        const unsigned so[3] = {(unsigned)m * hw4, (unsigned)((C + j0) >> 1) * hw4, (unsigned)((C + j1) >> 1) * hw4};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int p_ = 0; p_ < NP; ++p_)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_vp)(pl + (wv + 4 * j) * RS + 72 * p_ + 4), 4, vrow[j],
+                                                         so[p_ == 0 ? 0 : (CODD && p_ == 2) ? 2 : 1], 0, 0);
+        const rsrc_t rs = !live ? rdead : (wv == 0 ? rdw : rwp);
+        const unsigned v = (!CODD || 2 * m + sm_par < C) ? vsm : SW_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)(smb + 64 * wv), 4, v, (unsigned)((wv == 0 ? 72 : 8) * m), 0, 0);
+    };
+
+    f32x16 acc[R][MT];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][t][q] = 0.f;
+
+    // prologue: pair 0 complete in buffer 0, pair 1 on its way into buffer 1 with its edges in stage 1, pair 2 on its way into buffer 2
+    {
+        float q0[NP];
+        fetch_edges(0, q0);
+        dma(0, pl0, sm0);
+        fetch_edges(1, qe[1]);
+        dma(1, pl1, sm1);
+        dma(2, pl2, sm2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        park_edges(pl0, q0);
+    }
+    __syncthreads();
+
+    const int r0 = wy * R, col = wx * 32 + ln;
+    // step m: compute pair m from `cur`; edges of pair m + 2 -> stage m & 1; rows of pair m + 3 -> `far`; edges of pair m + 1 (stage (m + 1) & 1) -> `nxt`
+    auto pair_step = [&](int m, const float* cur, const float* smc, float* nxt, float* far, float* smf, float (&qnew)[NP], const float (&qold)[NP]) {
+        fetch_edges(m + 2, qnew);                        // (first: waiting for them later must not wait for this step's rows)
+        dma(m + 3, far, smf);
+        fdn_f32x2 wab[9];
+        float aw[MT];
+        {
+            const fdn_f32x2* dp = reinterpret_cast<const fdn_f32x2*>(smc) + kh * 10;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wab[i] = dp[i];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) aw[t] = smc[64 + kh * (MT * 32) + t * 32 + ln];
+        }
+        const float* pA = cur + r0 * RS + 3 + col;
+        const float* pB = pA + ((CODD && kh) ? 144 : 72);
+        fdn_f32x2 wAB[4][3];
+        auto load_row = [&](int hr, int k) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) wAB[k][dx] = fdn_f32x2{pA[hr * RS + dx], pB[hr * RS + dx]};
+        };
+        load_row(0, 0);
+        load_row(1, 1);
+        load_row(2, 2);
+        static_assert(R % 2 == 0, "rows are gated in pairs");
+#pragma unroll
+        for (int i = 0; i < R; i += 2) {
+            fdn_f32x2 sAB[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int ii = i + h2;
+                if (ii + 3 < R + 2) load_row(ii + 3, (ii + 3) & 3);
+                sAB[h2] = fdn_f32x2{0.f, 0.f};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) sAB[h2] = __builtin_elementwise_fma(wab[dy * 3 + dx], wAB[(ii + dy) & 3][dx], sAB[h2]);
+            }
+            const fdn_f32x2 val = gelu_fast2(fdn_f32x2{sAB[0].x, sAB[1].x}) * fdn_f32x2{sAB[0].y, sAB[1].y};      // gelu(x1) * x2, FDN_arch.py:473 / :427
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val.x, acc[i][t], 0, 0, 0);
+                acc[i + 1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], val.y, acc[i + 1][t], 0, 0, 0);
+            }
+        }
+        park_edges(nxt, qold);                           // pair m + 1's edge columns (requested a step ago, in front of that step's rows)
+        // pair m + 1's rows (requested two steps ago) have landed once at most this step's and the previous step's loads are outstanding
+        // (a bare barrier: __syncthreads() is a workgroup-scope release, and with direct-to-LDS loads in flight the compiler implements that as vmcnt(0))
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (CNT + NP)) : "memory");
+    };
+    {
+        int m = 0;
+        for (; m + 3 < npairs; m += 4) {                 // four steps per trip: the buffer of every step is a compile-time array
+            pair_step(m, pl0, sm0, pl1, pl3, sm3, qe[0], qe[1]);
+            pair_step(m + 1, pl1, sm1, pl2, pl0, sm0, qe[1], qe[0]);
+            pair_step(m + 2, pl2, sm2, pl3, pl1, sm1, qe[0], qe[1]);
+            pair_step(m + 3, pl3, sm3, pl0, pl2, sm2, qe[1], qe[0]);
+        }
+        if (m < npairs) pair_step(m, pl0, sm0, pl1, pl3, sm3, qe[0], qe[1]);
+        if (m + 1 < npairs) pair_step(m + 1, pl1, sm1, pl2, pl0, sm0, qe[1], qe[0]);
+        if (m + 2 < npairs) pair_step(m + 2, pl2, sm2, pl3, pl1, sm1, qe[0], qe[1]);
+    }
+    ffn_tail_epilogue<MT, R>(a, acc, b, ty0, tx0, r0, col, kh);
+}
+
 template <int MT, int R, bool IBF>
 int launch_sw(FtArgs a, hipStream_t s) {
     a.tiles_x = cdiv(a.W, SW_TC);
     a.tiles_per_img = a.tiles_x * cdiv(a.H, 2 * R);
     a.total_tiles = a.B * a.tiles_per_img;
+    if constexpr (FDN_TAIL_DMA && !IBF) {
+        if (a.C & 1) hipLaunchKernelGGL((ffn_tail_dma_kernel<MT, R, true>), dim3((unsigned)a.total_tiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ffn_tail_dma_kernel<MT, R, false>), dim3((unsigned)a.total_tiles), dim3(256), 0, s, a);
+        return fdn_launch_status();
+    }
     if (a.C & 1) hipLaunchKernelGGL((ffn_tail_sw_kernel<MT, R, IBF, true>), dim3((unsigned)a.total_tiles), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((ffn_tail_sw_kernel<MT, R, IBF, false>), dim3((unsigned)a.total_tiles), dim3(256), 0, s, a);
     return fdn_launch_status();
