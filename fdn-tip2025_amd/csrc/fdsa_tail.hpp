@@ -259,35 +259,17 @@ __device__ __forceinline__ void fdsa_tail_px2(const TailIo& io, const float* lds
 // Operand image (fdn_fdsa_tail_pack): [gamma 3 E2 | pad to 256 floats][beta 3 E2 | pad to 256][Wp [3][NQ][MT][part][64 lanes] 16-byte A operands].
 // The workgroup's 80 KB of LDS hold groups 0 and 1 (one in the dead hidden tile, one in the dead spectra: two arrays, so the compiler keeps the waits
 // of the two LDS-DMA batches apart); group 2's operands are read from the image itself (30 KB, L1 / L2 hits: the data loads bypass L1).
-#ifndef FDN_TAIL_CALL
-#define FDN_TAIL_CALL 0          // 1: the level-2 tail is a real function (its register allocation and the chunk loop's do not meet); 0: inlined
-#endif
-#if FDN_TAIL_CALL
-#define FDN_TAIL_FN __attribute__((noinline))
-#else
+// (the tail as a real function - to keep its register allocation away from the chunk loop's - measured slower: its callee-saved registers go through scratch,
+//  profiles/r06_tail_ab3.txt; it is inlined)
 #define FDN_TAIL_FN __forceinline__
-#endif
 typedef __attribute__((address_space(3))) const float* lds_cf;
 typedef __attribute__((address_space(3))) const fdn_u32x4* lds_cu4;
-// (a non-inlined device function receives its arguments in vector registers: the wave-uniform ones are made scalar again here)
-template <typename Tp>
-__device__ __forceinline__ Tp* tl_uniform_ptr(Tp* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<Tp*>(((unsigned long long)hi << 32) | lo);
-}
 // PIN (C = 64 only): the following FDFFN's project_in (64 -> Hd <= 32 NT) as gemm_split_strip_kernel<4, FDN_PRO_LN> computes it - see fdsa_tail_px2; its
 // packed operands ([NT][4 k-steps][3 parts][64 lanes] x 16 bytes, then 32 NT bias floats) are read from the image in global memory (72 KB: L1 / L2 hits)
 template <int SH, int MT, bool FULL = false, bool PIN = false, int NT = 6>          // FULL: E == 2 SH and N == 32 MT (the stock level 2: E = 76, C = 64): no channel-range predicates
-__device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo io_, lds_cf tg, lds_cf tb, lds_cu4 W0, lds_cu4 W1, const float* gimg_,
+__device__ FDN_TAIL_FN void fdsa_tail_px1(const TailIo& io, lds_cf tg, lds_cf tb, lds_cu4 W0, lds_cu4 W1, const float* gimg,
                                               unsigned long long* trc = nullptr) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
-    TailIo io;
-    io.scr = tl_uniform_ptr(io_.scr); io.res = tl_uniform_ptr(io_.res); io.y = tl_uniform_ptr(io_.y); io.stats_out = tl_uniform_ptr(io_.stats_out);
-    io.E = __builtin_amdgcn_readfirstlane(io_.E); io.N = __builtin_amdgcn_readfirstlane(io_.N); io.W = __builtin_amdgcn_readfirstlane(io_.W);
-    io.ty0 = __builtin_amdgcn_readfirstlane(io_.ty0); io.tx0 = __builtin_amdgcn_readfirstlane(io_.tx0); io.P = __builtin_amdgcn_readfirstlane(io_.P);
-    io.h = tl_uniform_ptr(io_.h); io.Hd = __builtin_amdgcn_readfirstlane(io_.Hd); io.h_bf16 = 0; io.ring_flag = tl_uniform_ptr(io_.ring_flag); io.ring_cnt = io_.ring_cnt;
-    const float* gimg = tl_uniform_ptr(gimg_);
     constexpr int E2 = 2 * SH, NQ = (SH + 7) / 8;
     const int E = io.E, N = io.N;
     const unsigned P = io.P, P4 = P * 4u;
