@@ -14,6 +14,8 @@ profiles/r03_cross_stream_probe.txt).  Within one stream kernels 
 outputs are bit-stable (tests/test_gpu_edge.py::test_single_stream_bit_stable).
 """
 import collections
+import contextlib
+import gc
 import os
 
 import torch
@@ -25,6 +27,23 @@ _streams = {}
 # from another thread, which the default ("global") capture mode would take for an illegal call during capture and abort the capture
 CAPTURE_MODE = "thread_local"
 MULTISTREAM_ENV = "FDN_HIP_ALLOW_MULTISTREAM"      # "1": allow n_streams > 1 (experiments; results are NOT bit-stable, see above)
+
+
+@contextlib.contextmanager
+def _capturing(graph):
+    """torch.cuda.graph(...) with Python's cyclic garbage collector held off for the duration of the capture.  A forward allocates thousands of Python
+    objects; a generational collection that starts INSIDE a capture can run the destructor of an older CUDAGraph / graph-private pool that has just
+    become unreachable (hipGraphExecDestroy, pool trimming) while this thread's stream is capturing.  (Round 6: two GPU-suite runs on fresh boxes aborted
+    inside the collector around the graph tests, "Fatal Python error: Aborted ... Garbage-collecting", never reproduced afterwards; torch itself collects
+    once on entry - this keeps the rest of the capture quiet too.)"""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode=CAPTURE_MODE):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def _check_streams(n_streams):
@@ -132,7 +151,7 @@ class GraphedForward:
                 self.net(static_x, ratio_i=self.lpnet(static_x), device=x.device)
         torch.cuda.current_stream(x.device).wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE), torch.no_grad():
+        with _capturing(g), torch.no_grad():
             static_out = self.net(static_x, ratio_i=self.lpnet(static_x), device=x.device)[0]
         return g, static_x, static_out, self._weights_signature()
 
@@ -185,7 +204,7 @@ class GraphedStep:
             torch.cuda.synchronize(x.device)
             self._g = torch.cuda.CUDAGraph()
             self._keep = {}
-            with torch.cuda.graph(self._g, capture_error_mode=CAPTURE_MODE):
+            with _capturing(self._g):
                 self._out = forward_streams(self.net, self.lpnet, self._x, self.n, keep=self._keep)
         self._x.copy_(x)
         self._g.replay()
